@@ -1,0 +1,177 @@
+"""ctypes binding to oracle/libmcpt_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+May be imported only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmcpt_oracle.so")
+
+
+def build(force=False):
+    src = [os.path.join(HERE, "mcpt_oracle.c"), os.path.join(HERE, "mcpt_oracle.h")]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
+        subprocess.check_call(["make", "-C", HERE, "libmcpt_oracle.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_objects", C.c_int32), ("n_triangles", C.c_int32), ("n_materials", C.c_int32),
+                ("env_w", C.c_int32), ("env_h", C.c_int32), ("background", C.c_float * 3),
+                ("objects", C.c_void_p), ("triangles", C.c_void_p), ("materials", C.c_void_p), ("env_pixels", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("spp", C.c_int32), ("rr_rate", C.c_float), ("n_dir_sample", C.c_int32), ("enable_shadow", C.c_int32),
+                ("seed", C.c_uint32), ("n_threads", C.c_int32), ("tile_size", C.c_int32), ("rank", C.c_int32),
+                ("nranks", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("scene_rays", C.c_uint64), ("vertices", C.c_uint64),
+                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("seconds", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_scene_create.restype = C.c_int
+        L.orc_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_render.restype = C.c_int
+        L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]
+        L.orc_intersect.restype = C.c_int
+        L.orc_intersect.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_cast_rays.restype = C.c_int
+        L.orc_cast_rays.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int64] + [C.c_void_p] * 6
+        L.orc_camera_ray.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_material_eval.restype = C.c_float
+        L.orc_material_eval.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int]
+        L.orc_material_pdf.restype = C.c_float
+        L.orc_material_pdf.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int]
+        L.orc_material_fresnel.restype = C.c_float
+        L.orc_material_fresnel.argtypes = [C.c_void_p] * 3 + [C.c_int]
+        L.orc_material_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+        L.orc_material_refract.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_philox4x32_10.argtypes = [C.c_void_p] * 3
+        L.orc_tonemap.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f3(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class OracleScene:
+    """Holds an orc_scene built from a SceneData (see the package's scenes.py for the POD layouts)."""
+
+    def __init__(self, sd):
+        self.sd = sd
+        self._tri = np.ascontiguousarray(sd.triangles)
+        self._mat = np.ascontiguousarray(sd.materials)
+        self._obj = np.ascontiguousarray(sd.objects)
+        d = SceneDesc()
+        d.n_objects, d.n_triangles, d.n_materials = len(self._obj), len(self._tri), len(self._mat)
+        d.background = (C.c_float * 3)(*[float(x) for x in sd.background])
+        d.objects, d.triangles, d.materials = _ptr(self._obj), _ptr(self._tri), _ptr(self._mat)
+        if sd.env_pixels is not None:
+            self._env = np.ascontiguousarray(sd.env_pixels, dtype=np.float32)
+            d.env_h, d.env_w = self._env.shape[:2]
+            d.env_pixels = _ptr(self._env)
+        h = C.c_void_p()
+        rc = lib().orc_scene_create(C.byref(d), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("orc_scene_create failed: %d" % rc)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().orc_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def params(self, spp=None, seed=1, n_threads=0, tile_size=32, rank=0, nranks=1, n_dir_sample=None):
+        sd = self.sd
+        return Params(spp=int(spp if spp is not None else sd.spp), rr_rate=float(sd.rr_rate),
+                      n_dir_sample=int(n_dir_sample if n_dir_sample is not None else sd.n_dir_sample),
+                      enable_shadow=int(sd.enable_shadow), seed=int(seed), n_threads=int(n_threads),
+                      tile_size=int(tile_size), rank=int(rank), nranks=int(nranks))
+
+    def render(self, camera=None, fb=None, **kw):
+        cam = np.ascontiguousarray(camera if camera is not None else self.sd.camera)
+        W, H = int(cam["width"]), int(cam["height"])
+        if fb is None:
+            fb = np.zeros((H, W, 3), dtype=np.float32)
+        p = self.params(**kw)
+        st = Stats()
+        rc = lib().orc_render(self.h, _ptr(cam), C.byref(p), _ptr(fb), C.byref(st))
+        if rc != 0:
+            raise RuntimeError("orc_render failed: %d" % rc)
+        return fb, st
+
+    def intersect(self, origins, dirs):
+        o, d = _f3(origins), _f3(dirs)
+        n = len(o)
+        t = np.zeros(n, dtype=np.float64)
+        prim = np.zeros(n, dtype=np.int32)
+        lib().orc_intersect(self.h, n, _ptr(o), _ptr(d), _ptr(t), _ptr(prim))
+        return t, prim
+
+    def cast_rays(self, origins, dirs, pixel, sample, channel, **kw):
+        o, d = _f3(origins), _f3(dirs)
+        n = len(o)
+        px = np.ascontiguousarray(pixel, dtype=np.uint32)
+        sm = np.ascontiguousarray(sample, dtype=np.uint32)
+        ch = np.ascontiguousarray(channel, dtype=np.int32)
+        out = np.zeros(n, dtype=np.float32)
+        p = self.params(**kw)
+        lib().orc_cast_rays(self.h, C.byref(p), n, _ptr(o), _ptr(d), _ptr(px), _ptr(sm), _ptr(ch), _ptr(out))
+        return out
+
+    def camera_rays(self, pixels, samples, seed=1, camera=None):
+        cam = np.ascontiguousarray(camera if camera is not None else self.sd.camera)
+        n = len(pixels)
+        o = np.zeros((n, 3), dtype=np.float32)
+        d = np.zeros((n, 3), dtype=np.float32)
+        for i in range(n):
+            lib().orc_camera_ray(_ptr(cam), seed, int(pixels[i]), int(samples[i]), C.c_void_p(o[i].ctypes.data),
+                                 C.c_void_p(d[i].ctypes.data))
+        return o, d
+
+
+def philox(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    o = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(_ptr(c), _ptr(k), _ptr(o))
+    return o
+
+
+def tonemap(fb):
+    fb = np.ascontiguousarray(fb, dtype=np.float32)
+    n = fb.size // 3
+    out = np.zeros((n, 4), dtype=np.uint8)
+    lib().orc_tonemap(_ptr(fb), n, _ptr(out))
+    return out.reshape(fb.shape[:-1] + (4,))
