@@ -1,0 +1,669 @@
+// C ABI of libmcpt_hip.so (include/mcpt.h) and the host-side wavefront loop.
+//
+// The loop replaces the pixel/spp loops of Renderer::Render (reference src/Renderer.cpp:36-90).  Samples are
+// streamed through a fixed pool of path records: every iteration shades all live records, refills the
+// pool with new camera samples ("path regeneration") and traces all rays of the iteration in two launches
+// (closest-hit queue, shadow queue), so the GPU always works on full, compacted queues.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mcpt_kernels.h"
+
+using namespace mcpt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? MCPT_ERR_OOM : MCPT_ERR_HIP,                        \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                             \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        else p = nullptr;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+template <typename T>
+hipError_t upload(DevBuf<T> &b, const std::vector<T> &v) {
+    hipError_t e = b.alloc(v.size());
+    if (e != hipSuccess) return e;
+    if (v.empty()) return hipSuccess;
+    return hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+struct WaveBufs {
+    DevBuf<uint4> rec0, hit;
+    DevBuf<float4> rec1, ray_o, ray_d, sh_org, sh_dir;
+    DevBuf<float> contrib;
+    Wave view() const { return Wave{rec0.p, rec1.p, ray_o.p, ray_d.p, hit.p, sh_org.p, sh_dir.p, contrib.p}; }
+    void release() {
+        rec0.release(); hit.release(); rec1.release(); ray_o.release(); ray_d.release();
+        sh_org.release(); sh_dir.release(); contrib.release();
+    }
+};
+
+struct Workspace {
+    uint32_t pool = 0;
+    int32_t n_dir = 0, max_depth = 0;
+    WaveBufs wave[2];
+    DevBuf<float4> stack;
+    DevBuf<float> result;
+    DevBuf<uint32_t> free_slots, pixel_list, key_pixel, key_sample;
+    DevBuf<int32_t> key_channel;
+    DevBuf<Counters> counters;
+    Counters *h_counters = nullptr;  // pinned
+    void release() {
+        wave[0].release(); wave[1].release(); stack.release(); result.release(); free_slots.release();
+        pixel_list.release(); key_pixel.release(); key_sample.release(); key_channel.release(); counters.release();
+        if (h_counters) (void)hipHostFree(h_counters);
+        h_counters = nullptr;
+        pool = 0;
+    }
+};
+
+enum KClass { K_CLOSEST = 0, K_SHADOW, K_SHADE, K_GENERATE, K_RESOLVE, K_NCLASS };
+
+struct Timer {
+    bool enabled = true;
+    std::vector<hipEvent_t> pool;
+    struct Rec { int a, b, cls; };
+    std::vector<Rec> recs;
+    size_t used = 0;
+    double ms[K_NCLASS] = {0, 0, 0, 0, 0};
+    uint64_t count[K_NCLASS] = {0, 0, 0, 0, 0};
+    int get() {
+        if (used == pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return -1;
+            pool.push_back(e);
+        }
+        return (int)used++;
+    }
+    int begin(hipStream_t s) {
+        if (!enabled) return -1;
+        const int a = get();
+        if (a >= 0) (void)hipEventRecord(pool[a], s);
+        return a;
+    }
+    void end(int a, int cls, hipStream_t s) {
+        count[cls]++;
+        if (!enabled || a < 0) return;
+        const int b = get();
+        if (b < 0) return;
+        (void)hipEventRecord(pool[b], s);
+        recs.push_back({a, b, cls});
+    }
+    void collect() {  // call after a stream sync
+        for (const Rec &r : recs) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, pool[r.a], pool[r.b]) == hipSuccess) ms[r.cls] += t;
+        }
+        recs.clear();
+        used = 0;
+    }
+    void reset() {
+        for (int i = 0; i < K_NCLASS; ++i) { ms[i] = 0; count[i] = 0; }
+        recs.clear();
+        used = 0;
+    }
+    void release() {
+        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+        pool.clear();
+    }
+};
+
+}  // namespace
+
+struct mcpt_scene {
+    int device = 0;
+    mcpt_scene_info info{};
+    DevBuf<Node> nodes;
+    DevBuf<TriGeom> tri_geom;
+    DevBuf<TriShade> tri_shade;
+    DevBuf<SphereRec> spheres;
+    DevBuf<MaterialRec> mats;
+    DevBuf<LightRec> lights;
+    DevBuf<LightNode> light_nodes;
+    DevBuf<LightTri> light_tris;
+    DevBuf<float> env;
+    DevScene view{};
+    Workspace ws;
+    Timer timer;
+};
+
+namespace {
+
+hipError_t ensure_workspace(mcpt_scene *sc, uint32_t pool, int32_t n_dir, int32_t max_depth, size_t n_result) {
+    Workspace &w = sc->ws;
+    hipError_t e;
+    const size_t n_rays = (size_t)pool + pool / 3 + 64;
+    for (int k = 0; k < 2; ++k) {
+        WaveBufs &b = w.wave[k];
+        if ((e = b.rec0.alloc(pool)) != hipSuccess) return e;
+        if ((e = b.rec1.alloc(pool)) != hipSuccess) return e;
+        if ((e = b.ray_o.alloc(n_rays)) != hipSuccess) return e;
+        if ((e = b.ray_d.alloc(n_rays)) != hipSuccess) return e;
+        if ((e = b.hit.alloc(n_rays)) != hipSuccess) return e;
+        if ((e = b.sh_org.alloc(pool)) != hipSuccess) return e;
+        if ((e = b.sh_dir.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
+        if ((e = b.contrib.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
+    }
+    if ((e = w.stack.alloc((size_t)pool * max_depth)) != hipSuccess) return e;
+    if ((e = w.result.alloc(n_result)) != hipSuccess) return e;
+    if ((e = w.free_slots.alloc(pool)) != hipSuccess) return e;
+    if ((e = w.counters.alloc(1)) != hipSuccess) return e;
+    if (!w.h_counters && (e = hipHostMalloc((void **)&w.h_counters, sizeof(Counters))) != hipSuccess) return e;
+    w.pool = pool;
+    w.n_dir = n_dir;
+    w.max_depth = max_depth;
+    return hipSuccess;
+}
+
+int derive_max_depth(const mcpt_params &p) {
+    if (p.max_depth > 0) return p.max_depth;
+    const double rr = std::min(std::max((double)p.rr_rate, 1e-6), 0.999999);
+    const int d = (int)std::ceil(std::log(1e-12) / std::log(rr));
+    return std::min(std::max(d, 8), 8192);
+}
+
+CameraConst make_camera(const mcpt_camera &c) {
+    CameraConst k;
+    std::memset(&k, 0, sizeof k);
+    k.width = c.width;
+    k.height = c.height;
+    k.use_dof = c.use_dof;
+    // Renderer.cpp:13,25-26: deg2rad(deg) = deg * M_PI(float) / 180.0 returned as float; scale = tan(...)
+    const float half = c.fov * 0.5f;
+    const float rad = (float)((double)(half * 3.141592653589793f) / 180.0);
+    k.scale = (float)std::tan((double)rad);
+    k.aspect = c.width / (float)c.height;
+    k.focal_distance = c.focal_distance;
+    k.aperture_radius = c.aperture_radius;
+    for (int i = 0; i < 3; ++i) k.eye[i] = c.position[i];
+    for (int i = 0; i < 9; ++i) k.orient[i] = c.orientation[i];
+    return k;
+}
+
+// Owned pixels in an order that keeps neighbouring list entries neighbouring on screen: tiles in
+// row-major order, 8x8 blocks inside a tile.
+void build_pixel_list(int W, int H, int tile, int rank, int nranks, std::vector<uint32_t> &out) {
+    out.clear();
+    if (tile <= 0) tile = 32;
+    if (nranks < 1) nranks = 1;
+    const int tx = (W + tile - 1) / tile, ty = (H + tile - 1) / tile;
+    for (int tj = 0; tj < ty; ++tj)
+        for (int ti = 0; ti < tx; ++ti) {
+            if (((tj * tx + ti) % nranks) != rank) continue;
+            const int x0 = ti * tile, y0 = tj * tile, x1 = std::min(W, x0 + tile), y1 = std::min(H, y0 + tile);
+            for (int by = y0; by < y1; by += 8)
+                for (int bx = x0; bx < x1; bx += 8)
+                    for (int y = by; y < std::min(y1, by + 8); ++y)
+                        for (int x = bx; x < std::min(x1, bx + 8); ++x) out.push_back((uint32_t)(y * W + x));
+        }
+}
+
+struct LoopTotals {
+    uint64_t iterations = 0, shaded = 0, closest = 0, shadow = 0, fresh_paths = 0;
+};
+
+// Runs the wavefront loop until `n_work` units (camera samples in mode 0, explicit paths in mode 1) are
+// done.  `result` receives one float per path id.
+int run_wavefront(mcpt_scene *sc, const RenderConst &C0, const CameraConst *cam, uint32_t n_work, hipStream_t st,
+                  LoopTotals &tot) {
+    Workspace &w = sc->ws;
+    Timer &T = sc->timer;
+    RenderConst C = C0;
+    const uint32_t pool = w.pool;
+    const int n_dir = C.n_dir;
+    launch_init_free(w.free_slots.p, w.counters.p, pool, st);
+    uint32_t n_free = pool;
+    uint32_t next_work = 0;
+    int cur = 0;
+    uint32_t n_paths = 0;    // records in wave[cur]
+    uint32_t n_pending = 0;  // of which the first n_pending have a pending vertex (and shadow rays)
+    uint32_t n_rays = 0;
+
+    // prologue: fill the pool
+    {
+        Wave nx = w.wave[cur].view();
+        if (C.mode == 0) {
+            const uint32_t g = std::min<uint32_t>(n_work, pool / 3);
+            int ev = T.begin(st);
+            launch_generate(*cam, C, nx, 0, g, 0, 0, n_free, st);
+            T.end(ev, K_GENERATE, st);
+            n_free -= 3 * g;
+            next_work = g;
+            n_paths = 3 * g;
+            n_rays = g;
+            tot.fresh_paths += 3ull * g;
+        } else {
+            // explicit rays were uploaded into wave[cur].ray_o/ray_d by the caller
+            launch_generate_explicit(C, nx, n_work, st);
+            HIP_TRY(hipMemsetAsync(&w.counters.p->n_free, 0, sizeof(uint32_t), st));
+            n_free = 0;
+            next_work = n_work;
+            n_paths = n_work;
+            n_rays = n_work;
+            tot.fresh_paths += n_work;
+        }
+        int ev = T.begin(st);
+        launch_trace_closest(sc->view, n_rays, nx.ray_o, nx.ray_d, nx.hit, st);
+        T.end(ev, K_CLOSEST, st);
+        tot.closest += n_rays;
+    }
+
+    while (n_paths > 0) {
+        Wave cw = w.wave[cur].view(), nx = w.wave[cur ^ 1].view();
+        HIP_TRY(hipMemsetAsync(w.counters.p, 0, 2 * sizeof(uint32_t), st));  // n_next, n_cont
+        int ev = T.begin(st);
+        launch_shade(sc->view, C, cw, nx, n_paths, st);
+        T.end(ev, K_SHADE, st);
+        HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        T.collect();
+        const uint32_t n_next = w.h_counters->n_next, n_cont = w.h_counters->n_cont;
+        n_free = w.h_counters->n_free;
+        tot.iterations++;
+        tot.shaded += n_next;
+
+        uint32_t g = 0;
+        if (C.mode == 0 && next_work < n_work) {
+            g = std::min<uint32_t>(n_work - next_work, std::min<uint32_t>((pool - n_next) / 3, n_free / 3));
+            ev = T.begin(st);
+            launch_generate(*cam, C, nx, next_work, g, n_next, n_cont, n_free, st);
+            T.end(ev, K_GENERATE, st);
+            next_work += g;
+            tot.fresh_paths += 3ull * g;
+        }
+        n_pending = n_next;
+        n_paths = n_next + 3 * g;
+        n_rays = n_cont + g;
+        ev = T.begin(st);
+        launch_trace_closest(sc->view, n_rays, nx.ray_o, nx.ray_d, nx.hit, st);
+        T.end(ev, K_CLOSEST, st);
+        tot.closest += n_rays;
+        if (C.enable_shadow && n_pending > 0) {
+            ev = T.begin(st);
+            launch_trace_shadow(sc->view, n_pending * (uint32_t)n_dir, n_dir, nx.sh_org, nx.sh_dir, nx.contrib, st);
+            T.end(ev, K_SHADOW, st);
+            tot.shadow += (uint64_t)n_pending * n_dir;
+        }
+        cur ^= 1;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    T.collect();
+    (void)n_pending;
+    return MCPT_OK;
+}
+
+int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, float *fb_dev, hipStream_t st,
+                mcpt_stats *stats) {
+    if (!sc || !cam || !pp || !fb_dev) return fail(MCPT_ERR_ARG, "mcpt_render: null argument");
+    const mcpt_params &p = *pp;
+    if (cam->width <= 0 || cam->height <= 0 || p.spp <= 0 || p.n_dir_sample <= 0 || !(p.rr_rate > 0.f))
+        return fail(MCPT_ERR_ARG, "mcpt_render: width/height/spp/n_dir_sample/rr_rate must be positive");
+    if ((uint64_t)cam->width * cam->height > 0x7fffffffull) return fail(MCPT_ERR_ARG, "mcpt_render: frame too large");
+    HIP_TRY(hipSetDevice(sc->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    Workspace &w = sc->ws;
+    const int W = cam->width, H = cam->height;
+
+    std::vector<uint32_t> pix;
+    build_pixel_list(W, H, p.tile_size, p.nranks > 1 ? p.rank : 0, p.nranks > 1 ? p.nranks : 1, pix);
+    const uint32_t n_pix = (uint32_t)pix.size();
+
+    int s_pass = p.spp_per_pass > 0 ? p.spp_per_pass : 32;
+    s_pass = std::min(s_pass, p.spp);
+    while ((uint64_t)n_pix * s_pass * 3ull > 0xfffffff0ull && s_pass > 1) s_pass /= 2;
+    const int max_depth = derive_max_depth(p);
+    uint64_t pool64 = p.pool_paths > 0 ? (uint64_t)p.pool_paths : (3ull << 20);
+    pool64 = std::max<uint64_t>(pool64, 3 * 256);
+    // keep the clamp stack within 48 GiB
+    while (pool64 * (uint64_t)max_depth * 16ull > (48ull << 30) && pool64 > 3 * 4096) pool64 /= 2;
+    pool64 = std::min<uint64_t>(pool64, std::max<uint64_t>(3ull * n_pix * (uint64_t)s_pass, 3 * 256));
+    const uint32_t pool = (uint32_t)(pool64 / 3 * 3);
+
+    if (!p.accumulate) HIP_TRY(hipMemsetAsync(fb_dev, 0, (size_t)W * H * 3 * sizeof(float), st));
+    if (n_pix == 0) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (stats) std::memset(stats, 0, sizeof *stats);
+        return MCPT_OK;
+    }
+    HIP_TRY(ensure_workspace(sc, pool, p.n_dir_sample, max_depth, (size_t)n_pix * s_pass * 3));
+    HIP_TRY(w.pixel_list.alloc(n_pix));
+    HIP_TRY(hipMemcpyAsync(w.pixel_list.p, pix.data(), (size_t)n_pix * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+
+    RenderConst C;
+    std::memset(&C, 0, sizeof C);
+    C.rr_rate = p.rr_rate;
+    C.inv_rr = 1 / p.rr_rate;  // Scene.hpp:112
+    C.n_dir = p.n_dir_sample;
+    C.enable_shadow = p.enable_shadow;
+    C.seed = p.seed;
+    C.mode = 0;
+    C.pixel_list = w.pixel_list.p;
+    C.max_depth = max_depth;
+    C.pool = pool;
+    C.stack = w.stack.p;
+    C.result = w.result.p;
+    C.free_slots = w.free_slots.p;
+    C.counters = w.counters.p;
+    const CameraConst cc = make_camera(*cam);
+    const float spp_total = (float)(p.spp_total > 0 ? p.spp_total : p.spp);
+
+    sc->timer.reset();
+    const char *tenv = std::getenv("MCPT_TIMING");
+    sc->timer.enabled = !(tenv && tenv[0] == '0');
+    LoopTotals tot;
+    uint64_t pushes = 0, overflow = 0;
+    for (int k0 = 0; k0 < p.spp; k0 += s_pass) {
+        const int s_now = std::min(s_pass, p.spp - k0);
+        C.s_pass = s_now;
+        C.sample_offset = p.sample_offset + k0;
+        const int rc = run_wavefront(sc, C, &cc, n_pix * (uint32_t)s_now, st, tot);
+        if (rc != MCPT_OK) return rc;
+        pushes += w.h_counters->pushes;
+        overflow += w.h_counters->overflow;
+        int ev = sc->timer.begin(st);
+        launch_accumulate(w.result.p, w.pixel_list.p, n_pix, s_now, spp_total, fb_dev, st);
+        sc->timer.end(ev, K_RESOLVE, st);
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    sc->timer.collect();
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->samples = (uint64_t)n_pix * p.spp;
+        stats->paths = 3 * stats->samples;
+        stats->vertices = stats->paths + pushes;
+        stats->shaded = tot.shaded;
+        stats->closest_rays = tot.closest;
+        stats->shadow_rays = tot.shadow;
+        // Scene::intersect calls of the reference: one per castRay invocation (Scene.cpp:87), n_dir per shaded
+        // vertex (Scene.cpp:73), one look-ahead per vertex that survives roulette (Scene.cpp:134,161).
+        const uint64_t cont = tot.closest - stats->samples;
+        stats->ref_scene_rays = stats->vertices + (uint64_t)p.n_dir_sample * tot.shaded + cont;
+        stats->iterations = tot.iterations;
+        stats->overflow_paths = overflow;
+        const Timer &T = sc->timer;
+        stats->ms_trace_closest = T.ms[K_CLOSEST];
+        stats->ms_trace_shadow = T.ms[K_SHADOW];
+        stats->ms_shade = T.ms[K_SHADE];
+        stats->ms_generate = T.ms[K_GENERATE];
+        stats->ms_resolve = T.ms[K_RESOLVE];
+        stats->n_trace_closest = T.count[K_CLOSEST];
+        stats->n_trace_shadow = T.count[K_SHADOW];
+        stats->n_shade = T.count[K_SHADE];
+        stats->n_generate = T.count[K_GENERATE];
+        stats->n_resolve = T.count[K_RESOLVE];
+        stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (overflow) return fail(MCPT_ERR_OVERFLOW, "some paths outran the clamp stack (raise params.max_depth)");
+    return MCPT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mcpt_last_error(void) { return g_err.c_str(); }
+const char *mcpt_version(void) { return "mcpt-hip 0.1 (gfx950)"; }
+
+int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out) {
+    if (!desc || !out) return fail(MCPT_ERR_ARG, "mcpt_scene_create: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(MCPT_ERR_HIP, "mcpt_scene_create: no HIP device available (this library has no CPU fallback)");
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= ndev) return fail(MCPT_ERR_ARG, "mcpt_scene_create: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    HostScene hs;
+    const char *err = "";
+    const int rc = build_host_scene(*desc, hs, &err);
+    if (rc != MCPT_OK) return fail(rc, std::string("mcpt_scene_create: ") + err);
+
+    mcpt_scene *sc = new (std::nothrow) mcpt_scene();
+    if (!sc) return fail(MCPT_ERR_OOM, "mcpt_scene_create: host allocation failed");
+    sc->device = device;
+    hipError_t e = hipSuccess;
+    auto up = [&](auto &buf, const auto &vec) {
+        if (e == hipSuccess) e = upload(buf, vec);
+    };
+    up(sc->nodes, hs.nodes);
+    up(sc->tri_geom, hs.tri_geom);
+    up(sc->tri_shade, hs.tri_shade);
+    up(sc->spheres, hs.spheres);
+    up(sc->mats, hs.materials);
+    up(sc->lights, hs.lights);
+    up(sc->light_nodes, hs.light_nodes);
+    up(sc->light_tris, hs.light_tris);
+    up(sc->env, hs.env);
+    if (e != hipSuccess) {
+        mcpt_scene_destroy(sc);
+        return fail(e == hipErrorOutOfMemory ? MCPT_ERR_OOM : MCPT_ERR_HIP, std::string("scene upload: ") + hipGetErrorString(e));
+    }
+    DevScene &v = sc->view;
+    v.nodes = sc->nodes.p;
+    v.tri_geom = sc->tri_geom.p;
+    v.tri_shade = sc->tri_shade.p;
+    v.spheres = sc->spheres.p;
+    v.mats = sc->mats.p;
+    v.lights = sc->lights.p;
+    v.light_nodes = sc->light_nodes.p;
+    v.light_tris = sc->light_tris.p;
+    v.env = sc->env.p;
+    for (int k = 0; k < 3; ++k) {
+        v.root_min[k] = hs.root_min[k];
+        v.root_max[k] = hs.root_max[k];
+        v.background[k] = hs.background[k];
+    }
+    v.root = hs.root;
+    v.n_tri = hs.n_triangles;
+    v.n_lights = (int32_t)hs.lights.size();
+    v.env_w = hs.env_w;
+    v.env_h = hs.env_h;
+    v.height = hs.height;
+    sc->info.n_nodes = (int32_t)hs.nodes.size();
+    sc->info.bvh_height = hs.height;
+    sc->info.n_lights = v.n_lights;
+    sc->info.n_prims = hs.n_triangles + hs.n_objects;
+    sc->info.scene_bytes = sc->nodes.bytes() + sc->tri_geom.bytes() + sc->tri_shade.bytes() + sc->spheres.bytes() +
+                           sc->mats.bytes() + sc->lights.bytes() + sc->light_nodes.bytes() + sc->light_tris.bytes() +
+                           sc->env.bytes();
+    *out = sc;
+    return MCPT_OK;
+}
+
+void mcpt_scene_destroy(mcpt_scene *sc) {
+    if (!sc) return;
+    (void)hipSetDevice(sc->device);
+    sc->ws.release();
+    sc->timer.release();
+    sc->nodes.release(); sc->tri_geom.release(); sc->tri_shade.release(); sc->spheres.release(); sc->mats.release();
+    sc->lights.release(); sc->light_nodes.release(); sc->light_tris.release(); sc->env.release();
+    delete sc;
+}
+
+int mcpt_scene_get_info(const mcpt_scene *sc, mcpt_scene_info *info) {
+    if (!sc || !info) return fail(MCPT_ERR_ARG, "mcpt_scene_get_info: null argument");
+    *info = sc->info;
+    return MCPT_OK;
+}
+
+int mcpt_render_device(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *p, float *fb_device, void *hip_stream,
+                       mcpt_stats *stats) {
+    return render_impl(sc, cam, p, fb_device, (hipStream_t)hip_stream, stats);
+}
+
+int mcpt_render(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *p, float *fb_host, mcpt_stats *stats) {
+    if (!sc || !cam || !p || !fb_host) return fail(MCPT_ERR_ARG, "mcpt_render: null argument");
+    HIP_TRY(hipSetDevice(sc->device));
+    const size_t n = (size_t)cam->width * cam->height * 3;
+    DevBuf<float> fb;
+    HIP_TRY(fb.alloc(n));
+    if (p->accumulate) HIP_TRY(hipMemcpy(fb.p, fb_host, n * sizeof(float), hipMemcpyHostToDevice));
+    const int rc = render_impl(sc, cam, p, fb.p, nullptr, stats);
+    if (rc == MCPT_OK || rc == MCPT_ERR_OVERFLOW) {
+        const hipError_t e = hipMemcpy(fb_host, fb.p, n * sizeof(float), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            fb.release();
+            return fail(MCPT_ERR_HIP, std::string("framebuffer download: ") + hipGetErrorString(e));
+        }
+    }
+    fb.release();
+    return rc;
+}
+
+int mcpt_intersect(mcpt_scene *sc, int64_t n, const float *origins, const float *dirs, double *out_t, int32_t *out_prim) {
+    if (!sc || n < 0 || (n > 0 && (!origins || !dirs || !out_t || !out_prim))) return fail(MCPT_ERR_ARG, "mcpt_intersect: bad argument");
+    if (n == 0) return MCPT_OK;
+    if (n > 0x7fffffff) return fail(MCPT_ERR_ARG, "mcpt_intersect: too many rays for one call");
+    HIP_TRY(hipSetDevice(sc->device));
+    std::vector<float4> o(n), d(n);
+    for (int64_t i = 0; i < n; ++i) {
+        o[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.f);
+        d[i] = make_float4(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], 0.f);
+    }
+    DevBuf<float4> dO, dD;
+    DevBuf<uint4> dH;
+    HIP_TRY(upload(dO, o));
+    HIP_TRY(upload(dD, d));
+    HIP_TRY(dH.alloc(n));
+    launch_trace_closest(sc->view, (uint32_t)n, dO.p, dD.p, dH.p, nullptr);
+    std::vector<uint4> h(n);
+    const hipError_t e = hipMemcpy(h.data(), dH.p, n * sizeof(uint4), hipMemcpyDeviceToHost);
+    dO.release(); dD.release(); dH.release();
+    if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("mcpt_intersect: ") + hipGetErrorString(e));
+    for (int64_t i = 0; i < n; ++i) {
+        const unsigned long long b = ((unsigned long long)h[i].y << 32) | h[i].x;
+        double t;
+        std::memcpy(&t, &b, sizeof t);
+        out_t[i] = t;
+        out_prim[i] = (int32_t)h[i].z;
+    }
+    return MCPT_OK;
+}
+
+int mcpt_cast_rays(mcpt_scene *sc, const mcpt_params *pp, int64_t n, const float *origins, const float *dirs,
+                   const uint32_t *pixel, const uint32_t *sample, const int32_t *channel, float *out) {
+    if (!sc || !pp || n < 0 || (n > 0 && (!origins || !dirs || !pixel || !sample || !channel || !out)))
+        return fail(MCPT_ERR_ARG, "mcpt_cast_rays: bad argument");
+    if (n == 0) return MCPT_OK;
+    const mcpt_params &p = *pp;
+    if (p.n_dir_sample <= 0 || !(p.rr_rate > 0.f)) return fail(MCPT_ERR_ARG, "mcpt_cast_rays: n_dir_sample/rr_rate must be positive");
+    for (int64_t i = 0; i < n; ++i)
+        if (channel[i] < 0 || channel[i] > 2) return fail(MCPT_ERR_ARG, "mcpt_cast_rays: channel must be 0..2");
+    HIP_TRY(hipSetDevice(sc->device));
+    Workspace &w = sc->ws;
+    const int max_depth = derive_max_depth(p);
+    const int64_t chunk_max = 1 << 20;
+    sc->timer.reset();
+    sc->timer.enabled = false;
+    for (int64_t base = 0; base < n; base += chunk_max) {
+        const uint32_t m = (uint32_t)std::min<int64_t>(chunk_max, n - base);
+        const uint32_t pool = std::max<uint32_t>((m + 2) / 3 * 3, 3 * 256);
+        HIP_TRY(ensure_workspace(sc, std::max(pool, w.pool), p.n_dir_sample, std::max(max_depth, w.max_depth), std::max<size_t>(m, w.result.n)));
+        HIP_TRY(w.key_pixel.alloc(m));
+        HIP_TRY(w.key_sample.alloc(m));
+        HIP_TRY(w.key_channel.alloc(m));
+        std::vector<float4> o(m), d(m);
+        for (uint32_t i = 0; i < m; ++i) {
+            const int64_t s = base + i;
+            o[i] = make_float4(origins[3 * s], origins[3 * s + 1], origins[3 * s + 2], 0.f);
+            d[i] = make_float4(dirs[3 * s], dirs[3 * s + 1], dirs[3 * s + 2], 0.f);
+        }
+        HIP_TRY(hipMemcpy(w.wave[0].ray_o.p, o.data(), m * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(w.wave[0].ray_d.p, d.data(), m * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(w.key_pixel.p, pixel + base, m * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(w.key_sample.p, sample + base, m * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(w.key_channel.p, channel + base, m * sizeof(int32_t), hipMemcpyHostToDevice));
+        RenderConst C;
+        std::memset(&C, 0, sizeof C);
+        C.rr_rate = p.rr_rate;
+        C.inv_rr = 1 / p.rr_rate;
+        C.n_dir = p.n_dir_sample;
+        C.enable_shadow = p.enable_shadow;
+        C.seed = p.seed;
+        C.mode = 1;
+        C.key_pixel = w.key_pixel.p;
+        C.key_sample = w.key_sample.p;
+        C.key_channel = w.key_channel.p;
+        C.max_depth = w.max_depth;
+        C.pool = w.pool;
+        C.stack = w.stack.p;
+        C.result = w.result.p;
+        C.free_slots = w.free_slots.p;
+        C.counters = w.counters.p;
+        LoopTotals tot;
+        const int rc = run_wavefront(sc, C, nullptr, m, nullptr, tot);
+        if (rc != MCPT_OK) return rc;
+        HIP_TRY(hipMemcpy(out + base, w.result.p, m * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return MCPT_OK;
+}
+
+int mcpt_camera_rays(mcpt_scene *sc, const mcpt_camera *cam, uint32_t seed, int64_t n, const uint32_t *pixel,
+                     const uint32_t *sample, float *origins, float *dirs) {
+    if (!sc || !cam || n < 0 || (n > 0 && (!pixel || !sample || !origins || !dirs))) return fail(MCPT_ERR_ARG, "mcpt_camera_rays: bad argument");
+    if (n == 0) return MCPT_OK;
+    if (n > 0x7fffffff) return fail(MCPT_ERR_ARG, "mcpt_camera_rays: too many rays for one call");
+    HIP_TRY(hipSetDevice(sc->device));
+    DevBuf<uint32_t> dP, dS;
+    DevBuf<float4> dO, dD;
+    HIP_TRY(dP.alloc(n));
+    HIP_TRY(dS.alloc(n));
+    HIP_TRY(dO.alloc(n));
+    HIP_TRY(dD.alloc(n));
+    HIP_TRY(hipMemcpy(dP.p, pixel, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dS.p, sample, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    launch_camera_rays(make_camera(*cam), seed, (uint32_t)n, dP.p, dS.p, dO.p, dD.p, nullptr);
+    std::vector<float4> o(n), d(n);
+    hipError_t e = hipMemcpy(o.data(), dO.p, n * sizeof(float4), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(d.data(), dD.p, n * sizeof(float4), hipMemcpyDeviceToHost);
+    dP.release(); dS.release(); dO.release(); dD.release();
+    if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("mcpt_camera_rays: ") + hipGetErrorString(e));
+    for (int64_t i = 0; i < n; ++i) {
+        origins[3 * i] = o[i].x; origins[3 * i + 1] = o[i].y; origins[3 * i + 2] = o[i].z;
+        dirs[3 * i] = d[i].x; dirs[3 * i + 1] = d[i].y; dirs[3 * i + 2] = d[i].z;
+    }
+    return MCPT_OK;
+}
+
+}  // extern "C"

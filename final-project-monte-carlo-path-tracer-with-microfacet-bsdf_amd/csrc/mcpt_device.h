@@ -1,0 +1,387 @@
+// Device-side math for the wavefront path tracer (gfx950).  Included only by mcpt_kernels.hip.
+//
+// Arithmetic contract: every expression keeps the reference's operand order and
+// precision class -- float vectors with Eigen's 3-term dot order x0*y0 + (x1*y1 + x2*y2), the double
+// det/u/v/t chain of Triangle::getIntersection, double sub-expressions wherever the reference source has a
+// double literal -- and the file is compiled with -ffp-contract=off, so that the same seeds give the
+// same paths as the CPU restatement except where libm (sinf/cosf) rounding flips a branch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mcpt_internal.h"
+
+namespace mcpt {
+
+struct f3 {
+    float x, y, z;
+};
+struct f2 {
+    float x, y;
+};
+
+#define MCPT_DI __device__ __forceinline__
+
+MCPT_DI f3 mk3(float x, float y, float z) { return {x, y, z}; }
+MCPT_DI f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+MCPT_DI f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+MCPT_DI f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
+MCPT_DI f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+MCPT_DI f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+MCPT_DI float dot(f3 a, f3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+MCPT_DI f3 cross(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+MCPT_DI float norm(f3 a) { return sqrtf(dot(a, a)); }
+MCPT_DI f3 normalized(f3 a) {  // Eigen normalized(): unchanged when the squared norm is 0
+    float z = dot(a, a);
+    if (z > 0.0f) return a / sqrtf(z);
+    return a;
+}
+MCPT_DI float comp(f3 a, int c) { return c == 0 ? a.x : (c == 1 ? a.y : a.z); }
+MCPT_DI float comp(const float *a, int c) { return a[c]; }
+
+// std::min / std::max / clamp of reference global.hpp:16-18 (a NaN v comes out as hi)
+MCPT_DI float std_min(float a, float b) { return (b < a) ? b : a; }
+MCPT_DI float std_max(float a, float b) { return (a < b) ? b : a; }
+MCPT_DI float clampf(float lo, float hi, float v) { return std_max(lo, std_min(hi, v)); }
+
+constexpr float kPi = 3.141592653589793f;  // global.hpp:8-9 (a float)
+
+// ---------------------------------------------------------------- Philox4x32-10
+struct RngKey {
+    uint32_t seed, pixel, sample, stream;
+};
+
+MCPT_DI void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+// One block = 4 uniforms in [0,1).  key = (seed, pixel); counter = (sample, depth, block, stream).
+MCPT_DI void rng_block(const RngKey &k, uint32_t depth, uint32_t block, float u[4]) {
+    uint32_t o[4];
+    philox4x32_10(k.sample, depth, block, k.stream, k.seed, k.pixel, o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = (float)(o[i] >> 8) * (1.0f / 16777216.0f);
+}
+
+// ---------------------------------------------------------------- scene view passed to kernels by value
+struct DevScene {
+    const Node *nodes;
+    const TriGeom *tri_geom;
+    const TriShade *tri_shade;
+    const SphereRec *spheres;
+    const MaterialRec *mats;
+    const LightRec *lights;
+    const LightNode *light_nodes;
+    const LightTri *light_tris;
+    const float *env;
+    float root_min[3], root_max[3];
+    float background[3];
+    int32_t root, n_tri, n_lights, env_w, env_h, height;
+};
+
+// ---------------------------------------------------------------- ray / box / primitive tests
+struct Ray {
+    f3 o, d, inv;
+};
+
+MCPT_DI Ray make_ray(f3 o, f3 d) {  // Ray.hpp:13-18: the inverse goes through a double division
+    Ray r;
+    r.o = o;
+    r.d = d;
+    r.inv = mk3((float)(1. / (double)d.x), (float)(1. / (double)d.y), (float)(1. / (double)d.z));
+    return r;
+}
+
+// Bounds3::IntersectP, Bounds3.hpp:95-108.  fmin/fmax ignore a NaN operand; the initializer-list
+// std::max/std::min keep a NaN that sits in the x slot.
+MCPT_DI bool box_hit(const float mn[3], const float mx[3], const Ray &r, float &tmin_out) {
+    const float t1x = (mn[0] - r.o.x) * r.inv.x, t1y = (mn[1] - r.o.y) * r.inv.y, t1z = (mn[2] - r.o.z) * r.inv.z;
+    const float t2x = (mx[0] - r.o.x) * r.inv.x, t2y = (mx[1] - r.o.y) * r.inv.y, t2z = (mx[2] - r.o.z) * r.inv.z;
+    const float lx = fminf(t1x, t2x), ly = fminf(t1y, t2y), lz = fminf(t1z, t2z);
+    const float hx = fmaxf(t1x, t2x), hy = fmaxf(t1y, t2y), hz = fmaxf(t1z, t2z);
+    float tmin = lx;
+    if (tmin < ly) tmin = ly;
+    if (tmin < lz) tmin = lz;
+    float tmax = hx;
+    if (hy < tmax) tmax = hy;
+    if (hz < tmax) tmax = hz;
+    tmin_out = tmin;
+    return (tmin - kEps <= tmax) && (tmax >= -kEps);
+}
+
+// Triangle::getIntersection, Triangle.hpp:222-252 (two-sided Moller-Trumbore, double det chain).
+MCPT_DI bool tri_hit(const TriGeom &g, const Ray &r, double &t_out, double &u_out, double &v_out) {
+    const f3 v0 = mk3(g.v0[0], g.v0[1], g.v0[2]);
+    const f3 e1 = mk3(g.e1x, g.e1yz[0], g.e1yz[1]);
+    const f3 e2 = mk3(g.e2xy[0], g.e2xy[1], g.e2z);
+    const f3 pvec = cross(r.d, e2);
+    const double det = (double)dot(e1, pvec);
+    if (fabs(det) < (double)kEps) return false;
+    const double det_inv = 1. / det;
+    const f3 tvec = r.o - v0;
+    const double u = (double)dot(tvec, pvec) * det_inv;
+    if (u < 0 || u > 1) return false;
+    const f3 qvec = cross(tvec, e1);
+    const double v = (double)dot(r.d, qvec) * det_inv;
+    if (v < 0 || u + v > 1) return false;
+    const double t = (double)dot(e2, qvec) * det_inv;
+    if (t < 0) return false;
+    t_out = t;
+    u_out = u;
+    v_out = v;
+    return true;
+}
+
+// solveQuadratic, global.hpp:20-35
+MCPT_DI bool solve_quadratic(float a, float b, float c, float &x0, float &x1) {
+    const float discr = b * b - 4 * a * c;
+    if (discr < 0) return false;
+    if (discr == 0) {
+        x0 = x1 = (float)(-0.5 * (double)b / (double)a);
+    } else {
+        const float q = (b > 0) ? (float)(-0.5 * (double)(b + sqrtf(discr))) : (float)(-0.5 * (double)(b - sqrtf(discr)));
+        x0 = q / a;
+        x1 = c / q;
+    }
+    if (x0 > x1) {
+        const float t = x0;
+        x0 = x1;
+        x1 = t;
+    }
+    return true;
+}
+
+// Sphere::getIntersection, Sphere.hpp:26-48
+MCPT_DI bool sphere_hit(const SphereRec &s, const Ray &r, float &t_out) {
+    const f3 L = r.o - mk3(s.c[0], s.c[1], s.c[2]);
+    const float a = dot(r.d, r.d);
+    const float b = 2 * dot(r.d, L);
+    const float c = dot(L, L) - s.radius2;
+    float t0, t1;
+    if (!solve_quadratic(a, b, c, t0, t1)) return false;
+    if (t0 < 0) t0 = t1;
+    if (t0 < 0) return false;
+    t_out = t0;
+    return true;
+}
+
+// ---------------------------------------------------------------- Material (Material.hpp)
+MCPT_DI float wavelen(int ch) { return ch == 0 ? 0.700f : (ch == 1 ? 0.5461f : 0.4358f); }  // WaveLen.hpp:7-18
+
+MCPT_DI float D_GGX(f3 h, f3 n, float alpha) {  // Material.hpp:26-34
+    const float NoH = fabsf(dot(n, h));
+    if (NoH <= kEps && NoH >= -kEps) return 0.0f;
+    const float tanTheta = sqrtf(1.0f - NoH * NoH) / NoH;
+    const float alpha2 = alpha * alpha;
+    const float denom = (NoH * NoH) * (alpha + tanTheta * tanTheta);
+    return alpha2 / (kPi * denom * denom);
+}
+
+MCPT_DI float G1_SmithGGX(f3 v, f3 n, float alpha) {  // Material.hpp:38-69
+    const float NoV = fabsf(dot(n, v));
+    if (NoV <= kEps && NoV >= -kEps) return 0.0f;
+    const float tanTheta = sqrtf(1.0f - NoV * NoV) / NoV;
+    if (tanTheta == 0.0f) return 1.0f;
+    const float al_tan = alpha * tanTheta;
+    return (float)(2. / (1. + (double)sqrtf(1 + al_tan * al_tan)));
+}
+
+MCPT_DI float G_SmithGGX(f3 wi, f3 wo, f3 n, float alpha) { return G1_SmithGGX(wi, n, alpha) * G1_SmithGGX(wo, n, alpha); }  // :70-77
+
+MCPT_DI float get_reflectance(const MaterialRec &m, f2 uv, int ch) {  // Material.hpp:134-151
+    if (!m.textured) return m.refl[ch];
+    const int col = (int)((uv.x - 0.05f) * 10);
+    const int row = (int)((uv.y - 0.00f) * 12);
+    if (col >= 3 && col <= 5 && row <= 7) {
+        const bool isWhite = (col + row) % 2 == 1;
+        return isWhite ? 0.9f : 0.1f;
+    }
+    return 0.1f;
+}
+
+MCPT_DI float fresnel_schlick(const MaterialRec &m, float cosTheta, f2 uv, int ch) {  // Material.hpp:80-86
+    const float f = get_reflectance(m, uv, ch);
+    const float invc = 1.f - cosTheta;
+    const float c2 = invc * invc;
+    return f + (1.f - f) * c2 * c2 * invc;
+}
+
+MCPT_DI f3 tan_to_world(f3 t, f3 n) {  // Material.hpp:95-106
+    f3 T;
+    if (fabsf(n.x) > fabsf(n.y)) {
+        const float invLen = 1.0f / sqrtf(n.x * n.x + n.z * n.z);
+        T = mk3(-n.z * invLen, 0.0f, n.x * invLen);
+    } else {
+        const float invLen = 1.0f / sqrtf(n.y * n.y + n.z * n.z);
+        T = mk3(0.0f, n.z * invLen, -n.y * invLen);
+    }
+    const f3 B = cross(n, T);
+    return (T * t.x + B * t.y) + n * t.z;
+}
+
+MCPT_DI f3 importance_sample_ggx(float xi_x, float xi_y, float alpha, f3 n) {  // Material.hpp:111-123
+    const float phi = 2.0f * kPi * xi_x;
+    const float cosTheta = sqrtf((1.0f - xi_y) / (1.0f + (alpha * alpha - 1.0f) * xi_y));
+    const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+    const f3 h = mk3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+    return normalized(tan_to_world(h, n));
+}
+
+MCPT_DI float get_ior(const MaterialRec &m, int ch) {  // Material.hpp:178-183
+    const float wl = wavelen(ch);
+    return m.iorA + m.iorB / (wl * wl);
+}
+
+MCPT_DI f3 mat_reflect(f3 I, f3 N) { return N * (2 * dot(N, I)) - I; }  // Material.hpp:195-197
+
+MCPT_DI float mat_fresnel(const MaterialRec &m, f3 I, f3 N, int ch) {  // Material.hpp:198-226
+    if (m.type == MCPT_SMOOTH_CONDUCTOR || m.type == MCPT_ROUGH_CONDUCTOR) return 1;
+    float cosi = clampf(-1, 1, dot(I, N));
+    float etai = 1, etat = get_ior(m, ch);
+    if (cosi > 0) {
+        const float t = etai;
+        etai = etat;
+        etat = t;
+    }
+    const float sint = etai / etat * sqrtf(std_max(0.f, 1 - cosi * cosi));
+    if (sint >= 1) return 1;
+    const float cost = sqrtf(std_max(0.f, 1 - sint * sint));
+    cosi = fabsf(cosi);
+    const float Rs = ((etat * cosi) - (etai * cost)) / ((etat * cosi) + (etai * cost));
+    const float Rp = ((etai * cosi) - (etat * cost)) / ((etai * cosi) + (etat * cost));
+    return (Rs * Rs + Rp * Rp) / 2;
+}
+
+MCPT_DI f3 mat_refract(const MaterialRec &m, f3 I, f3 N, int ch) {  // Material.hpp:227-242
+    float cosi = clampf(-1, 1, dot(I, N));
+    float etai = 1, etat = get_ior(m, ch);
+    f3 n = N;
+    if (cosi < 0) {
+        cosi = -cosi;
+    } else {
+        const float t = etai;
+        etai = etat;
+        etat = t;
+        n = -N;
+    }
+    const float eta = etai / etat;
+    const float k = 1 - eta * eta * (1 - cosi * cosi);
+    if (k < 0) return mk3(0, 0, 0);
+    return I * eta + n * (eta * cosi - sqrtf(k));
+}
+
+MCPT_DI f3 mat_sample(const MaterialRec &m, f3 N, float xi_x, float xi_y) {  // Material.hpp:268-281
+    if (m.type == MCPT_ROUGH_CONDUCTOR || m.type == MCPT_ROUGH_DIELECTRIC) return importance_sample_ggx(xi_x, xi_y, m.roughness, N);
+    return N;
+}
+
+MCPT_DI float eta_of(const MaterialRec &m, f3 wi, f3 N, int ch) {  // Material.hpp:299,318,360,393
+    const float ior = get_ior(m, ch);
+    return (dot(wi, N) > 0) ? ior : (float)(1. / (double)ior);
+}
+
+MCPT_DI float mat_pdf(const MaterialRec &m, f3 wi, f3 wo, f3 N, int ch, bool isReflect) {  // Material.hpp:285-328 (rough branch)
+    f3 h;
+    float jacobian;
+    if (isReflect) {
+        h = normalized(wi + wo);
+        h = (dot(wi, N) > 0) ? h : -h;
+        jacobian = 1.0f / (4.0f * fabsf(dot(h, wo)));
+    } else {
+        const float eta = eta_of(m, wi, N, ch);
+        const f3 hv = (-wi) - wo * eta;
+        h = normalized(hv);
+        const float d1 = dot(hv, hv);
+        jacobian = eta * eta * fabsf(dot(h, wo)) / d1;
+    }
+    const float D = D_GGX(h, N, m.roughness);
+    return D * dot(N, h) * jacobian;
+}
+
+MCPT_DI float mat_eval(const MaterialRec &m, f3 wi, f3 wo, f3 N, int ch, f2 uv, bool isReflect) {  // Material.hpp:330-408
+    const bool rough = (m.type == MCPT_ROUGH_CONDUCTOR || m.type == MCPT_ROUGH_DIELECTRIC);
+    if (rough) {
+        if (isReflect) {
+            if (dot(wi, N) * dot(wo, N) <= 0) return 0.f;
+            f3 h = normalized(wi + wo);
+            h = dot(wi, N) > 0 ? h : -h;
+            const float F = (m.type == MCPT_ROUGH_CONDUCTOR) ? fresnel_schlick(m, fabsf(dot(h, wo)), uv, ch) : mat_fresnel(m, -wi, h, ch);
+            const float D = D_GGX(h, N, m.roughness);
+            const float G = G_SmithGGX(wi, wo, h, m.roughness);
+            const float denom = 4.0f * fabsf(dot(N, wi)) * fabsf(dot(N, wo)) + kEps;
+            return F * D * G / denom;
+        }
+        if (m.type == MCPT_ROUGH_CONDUCTOR || dot(wi, N) * dot(wo, N) >= 0) return 0.f;
+        const float eta = eta_of(m, wi, N, ch);
+        f3 h = normalized((-wi) - wo * eta);
+        h = dot(h, N) > 0 ? h : -h;
+        const float F = mat_fresnel(m, -wi, h, ch);
+        const float D = D_GGX(h, N, m.roughness);
+        const float G = G_SmithGGX(wi, wo, h, m.roughness);
+        const float hol = dot(h, wi);
+        const float hov = dot(h, wo);
+        float den = hol + eta * hov;
+        den *= den;
+        den *= fabsf(dot(N, wi) * dot(N, wo));
+        return (1.0f - F) * D * G * eta * eta * fabsf(hol * hov) / den;
+    }
+    if (isReflect) {
+        f3 h = normalized(wi + wo);
+        h = (dot(wi, N) > 0) ? h : -h;
+        if (dot(wi, N) * dot(wo, N) <= 0 || dot(h, N) < 1 - kEps) return 0.f;
+        return (m.type == MCPT_SMOOTH_CONDUCTOR) ? fresnel_schlick(m, fabsf(dot(N, wo)), uv, ch) : mat_fresnel(m, -wi, N, ch);
+    }
+    const float eta = eta_of(m, wi, N, ch);
+    f3 h = normalized((-wi) - wo * eta);
+    h = (dot(h, N) > 0) ? h : -h;
+    if (m.type == MCPT_SMOOTH_CONDUCTOR || dot(wi, N) * dot(wo, N) >= 0 || dot(h, N) < 1 - kEps) return 0.f;
+    return (float)(1. - (double)mat_fresnel(m, -wi, N, ch));
+}
+
+// ---------------------------------------------------------------- environment, Scene.hpp:60-99
+MCPT_DI f3 sample_env(const DevScene &S, f3 dir) {
+    if (S.env_w <= 0) return mk3(S.background[0], S.background[1], S.background[2]);
+    const f3 d = normalized(dir);
+    const float phi = atan2f(d.z, d.x);
+    const float theta = acosf(d.y);
+    float u = (phi + kPi) / (2.f * kPi);
+    float v = theta / kPi;
+    u = u - floorf(u);
+    v = v < 0.f ? 0.f : (1.f < v ? 1.f : v);
+    const float x = u * S.env_w - 0.5f;
+    const float y = v * S.env_h - 0.5f;
+    const int x0 = (int)floorf(x);
+    const int y0 = (int)floorf(y);
+    const int W = S.env_w, H = S.env_h;
+    int X0 = x0 % W;
+    if (X0 < 0) X0 += W;
+    int X1 = (x0 + 1) % W;
+    if (X1 < 0) X1 += W;
+    const int Y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0);
+    const int Y1 = y0 + 1 < 0 ? 0 : (y0 + 1 > H - 1 ? H - 1 : y0 + 1);
+    const float sx = x - x0, sy = y - y0;
+    const float *e = S.env;
+    const f3 c00 = mk3(e[3 * ((size_t)Y0 * W + X0)], e[3 * ((size_t)Y0 * W + X0) + 1], e[3 * ((size_t)Y0 * W + X0) + 2]);
+    const f3 c10 = mk3(e[3 * ((size_t)Y0 * W + X1)], e[3 * ((size_t)Y0 * W + X1) + 1], e[3 * ((size_t)Y0 * W + X1) + 2]);
+    const f3 c01 = mk3(e[3 * ((size_t)Y1 * W + X0)], e[3 * ((size_t)Y1 * W + X0) + 1], e[3 * ((size_t)Y1 * W + X0) + 2]);
+    const f3 c11 = mk3(e[3 * ((size_t)Y1 * W + X1)], e[3 * ((size_t)Y1 * W + X1) + 1], e[3 * ((size_t)Y1 * W + X1) + 2]);
+    const f3 c0 = c00 * (1 - sx) + c10 * sx;
+    const f3 c1 = c01 * (1 - sx) + c11 * sx;
+    return c0 * (1 - sy) + c1 * sy;
+}
+
+}  // namespace mcpt

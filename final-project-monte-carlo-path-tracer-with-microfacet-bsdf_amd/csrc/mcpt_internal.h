@@ -1,0 +1,121 @@
+// Internal layouts shared by the host scene builder, the kernels and the C-ABI layer.
+// Everything here is resident in HBM for the lifetime of an mcpt_scene.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/mcpt.h"
+
+namespace mcpt {
+
+constexpr float kEps = 1e-4f;                 // EPSILON, reference Renderer.cpp:15
+constexpr int kNoChild = 0x7fffffff;          // absent child
+constexpr int kMaxBvhHeight = 48;             // traversal stack entries per lane (LDS)
+constexpr int kMaxLightTreeDepth = 64;
+
+// BVH2 node, 64 bytes = four 16-byte loads.  Both children's boxes live in the parent so that one
+// fetch decides both descents.  child >= 0: inner node index; child < 0: leaf, primitive id = ~child;
+// kNoChild: absent.  Topology mirrors the reference's two-level median-split trees (BVH.cpp:27-93)
+// flattened into one array: a scene-level leaf that is a mesh is replaced by the mesh's own root.
+struct alignas(16) Node {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;
+    int32_t pad[2];
+};
+static_assert(sizeof(Node) == 64, "Node must be 64 bytes");
+
+// Traversal-side triangle record (48 bytes, three 16-byte loads): what Triangle::getIntersection reads
+// (Triangle.hpp:222-252): v0, e1, e2.
+struct alignas(16) TriGeom {
+    float v0[3];
+    float e1x;
+    float e1yz[2];
+    float e2xy[2];
+    float e2z;
+    int32_t pad[3];
+};
+static_assert(sizeof(TriGeom) == 48, "TriGeom must be 48 bytes");
+
+// Shading-side triangle record (48 bytes): normal, material, texture coords (Triangle.hpp:45-48).
+struct alignas(16) TriShade {
+    float n[3];
+    int32_t mat;
+    float t0[2], t1[2];
+    float t2[2];
+    int32_t pad[2];
+};
+static_assert(sizeof(TriShade) == 48, "TriShade must be 48 bytes");
+
+struct alignas(16) SphereRec {  // Sphere.hpp:14-18
+    float c[3];
+    float radius;
+    float radius2;
+    int32_t mat;
+    int32_t pad[2];
+};
+static_assert(sizeof(SphereRec) == 32, "SphereRec must be 32 bytes");
+
+struct alignas(16) MaterialRec {  // Material.hpp:157-167
+    int32_t type, textured, isDirac, hasEmission;
+    float roughness, iorA, iorB, pad0;
+    float refl[3], pad1;
+    float emit[3], pad2;
+};
+static_assert(sizeof(MaterialRec) == 64, "MaterialRec must be 64 bytes");
+
+// Light table entry: one per emissive object, in Scene::Add order (Scene.hpp:106-108).
+struct alignas(16) LightRec {
+    float area;        // Object::getArea()
+    int32_t kind;      // MCPT_OBJ_MESH / MCPT_OBJ_SPHERE
+    int32_t root;      // mesh: index of the root LightNode; sphere: sphere index
+    int32_t mat;
+    float root_area;   // mesh: BVHBuildNode::area of the mesh root (BVH.cpp:45-46,91)
+    int32_t pad[3];
+};
+static_assert(sizeof(LightRec) == 32, "LightRec must be 32 bytes");
+
+// Area tree of a light mesh, for BVHAccel::getSample (BVH.cpp:118-129).
+struct alignas(16) LightNode {
+    float left_area;   // node->left->area
+    int32_t left;      // child LightNode index, or ~(LightTri index) when the child is a leaf
+    int32_t right;
+    float area;        // node->area
+};
+static_assert(sizeof(LightNode) == 16, "LightNode must be 16 bytes");
+
+// Triangle of an emissive mesh, for Triangle::Sample (Triangle.hpp:71-76): it interpolates the STORED
+// vertices, which cannot be rebuilt exactly from TriGeom's edges, so light triangles keep their own copy.
+struct alignas(16) LightTri {
+    float v0[3], v1[3], v2[3];
+    float n[3];
+    float area;
+    int32_t pad[3];
+};
+static_assert(sizeof(LightTri) == 64, "LightTri must be 64 bytes");
+
+// Host-side product of scene construction, ready to be copied to the device.
+struct HostScene {
+    std::vector<Node> nodes;
+    std::vector<TriGeom> tri_geom;
+    std::vector<TriShade> tri_shade;
+    std::vector<float> tri_area;
+    std::vector<SphereRec> spheres;       // indexed by object index (entries for meshes unused)
+    std::vector<MaterialRec> materials;
+    std::vector<LightRec> lights;
+    std::vector<LightNode> light_nodes;
+    std::vector<LightTri> light_tris;
+    float root_min[3], root_max[3];       // scene root bounds (tested once per ray, BVH.cpp:105)
+    int32_t root;                         // root child reference (inner index or leaf)
+    int32_t n_triangles = 0, n_objects = 0;
+    int32_t height = 0;
+    float background[3];
+    int32_t env_w = 0, env_h = 0;
+    std::vector<float> env;
+    float light_area_sum = 0.f;
+};
+
+// Builds the flattened scene.  Returns MCPT_OK or an error code and fills `err`.
+int build_host_scene(const mcpt_scene_desc &d, HostScene &out, const char **err);
+
+}  // namespace mcpt

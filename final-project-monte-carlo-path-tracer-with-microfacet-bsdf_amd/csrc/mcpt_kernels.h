@@ -1,0 +1,74 @@
+// Kernel-launch interface between the C-ABI layer (mcpt_api.cpp) and the HIP kernels (mcpt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mcpt_device.h"
+
+namespace mcpt {
+
+// Path record flags (rec0.z): depth in the low 16 bits.
+constexpr uint32_t kFresh = 1u << 16;      // no pending vertex: the record's ray is the path's first ray
+constexpr uint32_t kTerminate = 1u << 17;  // Russian roulette failed at the pending vertex (Scene.cpp:129,156)
+constexpr uint32_t kInside = 1u << 18;     // wo.n < 0 at the pending vertex (Scene.cpp:115)
+
+// Device counters, reset/read by the host once per wavefront iteration.
+struct Counters {
+    uint32_t n_next;    // records appended to the next path list
+    uint32_t n_cont;    // continuation rays appended to the next closest-hit queue
+    uint32_t n_free;    // entries in the free-slot stack
+    uint32_t pushes;    // cumulative: recursion levels entered (castRay depth+1 calls)
+    uint32_t overflow;  // cumulative: paths cut by max_depth
+    uint32_t finished;  // cumulative: finished paths
+    uint32_t pad[2];
+};
+
+// One side of the double-buffered wavefront state (all SoA, 16-byte records, indexed by list position).
+struct Wave {
+    uint4 *rec0;      // {pid, ray index, depth|flags, kr bits}
+    float4 *rec1;     // {eval, |wo.n| or -1 for Dirac, pdf, clamp-stack slot bits}
+    float4 *ray_o;    // closest-hit queue: origin
+    float4 *ray_d;    // closest-hit queue: direction
+    uint4 *hit;       // closest-hit results: {t lo, t hi, prim, 0}
+    float4 *sh_org;   // shadow rays: origin, one per path record
+    float4 *sh_dir;   // shadow rays: {direction, distance to the light sample}, n_dir per path record
+    float *contrib;   // per shadow ray: light-sample contribution; zeroed by the shadow kernel when occluded
+};
+
+struct RenderConst {
+    float rr_rate, inv_rr;
+    int32_t n_dir, enable_shadow;
+    uint32_t seed;
+    int32_t mode;  // 0: pid -> (pixel list, sample); 1: explicit per-path keys (mcpt_cast_rays)
+    const uint32_t *pixel_list;
+    int32_t s_pass, sample_offset;
+    const uint32_t *key_pixel, *key_sample;
+    const int32_t *key_channel;
+    int32_t max_depth;
+    uint32_t pool;  // clamp-stack row length (slots)
+    float4 *stack;  // [level][slot] = {clamp(0,15,l_dir), eval, |wo.n| or -1, pdf}
+    float *result;  // per pid: castRay(ray, 0, channel)
+    uint32_t *free_slots;
+    Counters *counters;
+};
+
+struct CameraConst {
+    int32_t width, height, use_dof;
+    float scale, aspect, focal_distance, aperture_radius;
+    float eye[3];
+    float orient[9];
+};
+
+void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, hipStream_t s);
+void launch_generate(const CameraConst &cam, const RenderConst &C, Wave next, uint32_t first_sample, uint32_t n_samples,
+                     uint32_t path_base, uint32_t ray_base, uint32_t n_free_before, hipStream_t s);
+void launch_generate_explicit(const RenderConst &C, Wave next, uint32_t n, hipStream_t s);
+void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const uint32_t *pixel, const uint32_t *sample,
+                        float4 *o, float4 *d, hipStream_t s);
+void launch_trace_closest(const DevScene &S, uint32_t n, const float4 *ray_o, const float4 *ray_d, uint4 *hit, hipStream_t s);
+void launch_trace_shadow(const DevScene &S, uint32_t n_rays, int32_t n_dir, const float4 *sh_org, const float4 *sh_dir,
+                         float *contrib, hipStream_t s);
+void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, uint32_t n_cur, hipStream_t s);
+void launch_accumulate(const float *result, const uint32_t *pixel_list, uint32_t n_pix, int32_t s_pass, float spp_total,
+                       float *fb, hipStream_t s);
+
+}  // namespace mcpt

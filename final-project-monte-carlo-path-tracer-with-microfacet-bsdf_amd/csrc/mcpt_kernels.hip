@@ -1,0 +1,580 @@
+// HIP kernels of the wavefront path tracer for gfx950 (MI355X, CDNA4; 64-wide wavefronts).
+//
+// Pipeline per wavefront iteration (host loop in mcpt_api.cpp):
+//   k_shade          one lane per path record: resolves the pending vertex (direct-light sum, continuation
+//                    hit), finishes the path or pushes a clamp-stack level, shades the next vertex and emits
+//                    n_dir shadow rays + at most one continuation ray; survivors are stream-compacted into
+//                    the next list with ballot/popcount wave-aggregated atomics.
+//   k_generate       camera rays for new samples (one primary ray feeds the three channel paths).
+//   k_trace<false>   closest hit for primary + continuation rays.
+//   k_trace<true>    shadow rays: the distance-equality visibility of Scene.cpp:75.
+//   k_accumulate     per pass: framebuffer[m] += rgb/spp in sample order (Renderer.cpp:80).
+//
+// Reference logic covered: Renderer.cpp:39-80, Scene.cpp:19-37,56-184, BVH.cpp:95-135,
+// Bounds3.hpp:95-108, Triangle.hpp:71-76,193-196,222-252, Sphere.hpp:26-48, Material.hpp:26-408.
+#include <cfloat>
+
+#include "mcpt_kernels.h"
+
+namespace mcpt {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+MCPT_DI uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Wave-aggregated slot allocation: one atomic per wavefront, prefix by mbcnt over the ballot mask.
+// Must be called by all lanes of the wave at a converged point.
+MCPT_DI uint32_t wave_alloc(bool want, uint32_t *counter) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return 0u;
+    const uint32_t total = (uint32_t)__popcll(mask);
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane_id() == leader) base = atomicAdd(counter, total);
+    base = (uint32_t)__shfl((int)base, leader);
+    return base + prefix;
+}
+
+MCPT_DI void wave_count(bool want, uint32_t *counter) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return;
+    const int leader = __ffsll((long long)mask) - 1;
+    if ((int)lane_id() == leader) atomicAdd(counter, (uint32_t)__popcll(mask));
+}
+
+MCPT_DI f3 ld3(float4 v) { return mk3(v.x, v.y, v.z); }
+
+// ------------------------------------------------------------------------------------------------
+// Traversal.  One lane per ray; the per-lane stack of child references lives in LDS as
+// stk[level][thread] so that the 64 lanes of a wave hit 64 consecutive banks.
+//
+// Result equivalence with BVHAccel::getIntersection (BVH.cpp:103-116), which visits both children and
+// never prunes: a primitive is tested here only if every ancestor box test of the reference passes
+// (same box test, same tree), children are visited near-first, and a subtree is skipped only when its
+// entry distance exceeds the best hit by a margin far above float rounding (closest hit) or lies beyond
+// the light sample (shadow rays).  Equal distances go to the larger primitive id.
+// ------------------------------------------------------------------------------------------------
+template <bool SHADOW, int STK>
+__global__ __launch_bounds__(kBlock) void k_trace(DevScene S, uint32_t n, const float4 *__restrict__ ray_o,
+                                                  const float4 *__restrict__ ray_d, uint4 *__restrict__ hit,
+                                                  int32_t n_dir, const float4 *__restrict__ sh_org,
+                                                  const float4 *__restrict__ sh_dir, float *__restrict__ contrib) {
+    __shared__ int32_t stk[STK][kBlock];
+    const int tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * kBlock + tid;
+    if (i >= n) return;
+
+    f3 o, d;
+    float dist = 0.f;
+    if (SHADOW) {
+        const float4 dd = sh_dir[i];
+        o = ld3(sh_org[i / (uint32_t)n_dir]);
+        d = ld3(dd);
+        dist = dd.w;
+    } else {
+        o = ld3(ray_o[i]);
+        d = ld3(ray_d[i]);
+    }
+    const Ray r = make_ray(o, d);
+
+    double best_t = DBL_MAX;
+    int32_t best_prim = -1;
+    bool occluded = false, found = false;
+    float lim = SHADOW ? (dist + (dist * 1e-4f + 1e-2f)) : INFINITY;
+
+    float tm;
+    if (box_hit(S.root_min, S.root_max, r, tm)) {
+        int32_t cur = S.root;
+        int sp = 0;
+        while (true) {
+            if (cur >= 0) {
+                const float4 *np = reinterpret_cast<const float4 *>(S.nodes + cur);
+                const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+                const float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
+                const float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
+                const int32_t left = __float_as_int(e.x), right = __float_as_int(e.y);
+                float tl = 0.f, tr = 0.f;
+                bool hl = (left != kNoChild) && box_hit(lmin, lmax, r, tl);
+                bool hr = (right != kNoChild) && box_hit(rmin, rmax, r, tr);
+                hl = hl && !(tl > lim);
+                hr = hr && !(tr > lim);
+                if (hl && hr) {
+                    const bool swap = tr < tl;
+                    const int32_t nearc = swap ? right : left, farc = swap ? left : right;
+                    if (sp < STK) stk[sp++][tid] = farc;
+                    cur = nearc;
+                    continue;
+                }
+                if (hl) {
+                    cur = left;
+                    continue;
+                }
+                if (hr) {
+                    cur = right;
+                    continue;
+                }
+            } else {
+                const int32_t prim = ~cur;
+                double t = 0, u, v;
+                bool h;
+                if (prim < S.n_tri) {
+                    h = tri_hit(S.tri_geom[prim], r, t, u, v);
+                } else {
+                    float ts = 0.f;
+                    h = sphere_hit(S.spheres[prim - S.n_tri], r, ts);
+                    t = (double)ts;
+                }
+                if (h) {
+                    if (SHADOW) {
+                        const double dd = t - (double)dist;
+                        if (dd <= -(double)kEps) {
+                            occluded = true;
+                            break;
+                        }
+                        if (fabs(dd) < (double)kEps) found = true;
+                    } else if (t < best_t || (t == best_t && prim > best_prim)) {
+                        best_t = t;
+                        best_prim = prim;
+                        lim = (float)(t + (fabs(t) * 1e-4 + 1e-2));
+                    }
+                }
+            }
+            if (sp == 0) break;
+            cur = stk[--sp][tid];
+        }
+    }
+
+    if (SHADOW) {
+        // Scene.cpp:74-75: the sample counts iff the CLOSEST hit lies within EPSILON of the light distance.
+        if (occluded || !found) contrib[i] = 0.f;
+    } else {
+        const unsigned long long tb = (unsigned long long)__double_as_longlong(best_t);
+        hit[i] = make_uint4((uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)best_prim, 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Path keys
+// ------------------------------------------------------------------------------------------------
+MCPT_DI void path_key(const RenderConst &C, uint32_t pid, RngKey &key, int &ch) {
+    if (C.mode == 0) {
+        ch = (int)(pid % 3u);
+        const uint32_t s = pid / 3u;
+        const uint32_t pl = s / (uint32_t)C.s_pass;
+        key.pixel = C.pixel_list ? C.pixel_list[pl] : pl;
+        key.sample = (uint32_t)C.sample_offset + (s % (uint32_t)C.s_pass);
+    } else {
+        ch = C.key_channel[pid];
+        key.pixel = C.key_pixel[pid];
+        key.sample = C.key_sample[pid];
+    }
+    key.seed = C.seed;
+    key.stream = (uint32_t)ch;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Camera rays, Renderer.cpp:44-76
+// ------------------------------------------------------------------------------------------------
+MCPT_DI f3 mat3_mul(const float *M, f3 v) {
+    return mk3(M[0] * v.x + (M[1] * v.y + M[2] * v.z), M[3] * v.x + (M[4] * v.y + M[5] * v.z), M[6] * v.x + (M[7] * v.y + M[8] * v.z));
+}
+
+MCPT_DI void camera_ray(const CameraConst &cam, uint32_t seed, uint32_t m, uint32_t k, f3 &pos, f3 &dir) {
+    const int i = (int)(m % (uint32_t)cam.width), j = (int)(m / (uint32_t)cam.width);
+    RngKey rk{seed, m, k, 3u};
+    float u[4];
+    rng_block(rk, 0u, 0u, u);
+    const f3 eye = mk3(cam.eye[0], cam.eye[1], cam.eye[2]);
+    const float x = (1 - 2 * (i + u[0]) / (float)cam.width) * cam.aspect * cam.scale;
+    const float y = (1 - 2 * (j + u[1]) / (float)cam.height) * cam.scale;
+    if (cam.use_dof) {
+        const f3 focal_point = mk3(x, y, 1) * cam.focal_distance;
+        const float r = cam.aperture_radius * sqrtf(u[2]);
+        const float theta = 2 * kPi * u[3];
+        const float dx = r * cosf(theta);
+        const float dy = r * sinf(theta);
+        pos = eye + mat3_mul(cam.orient, mk3(dx, dy, 0));
+        dir = normalized(focal_point - mk3(dx, dy, 0));
+    } else {
+        dir = normalized(mk3(x, y, 1));
+        pos = eye;
+    }
+    dir = mat3_mul(cam.orient, dir);  // Renderer.cpp:76
+}
+
+__global__ __launch_bounds__(kBlock) void k_generate(CameraConst cam, RenderConst C, Wave next, uint32_t first_sample,
+                                                     uint32_t n_samples, uint32_t path_base, uint32_t ray_base,
+                                                     uint32_t n_free_before) {
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n_samples) return;
+    const uint32_t s = first_sample + j;
+    const uint32_t pl = s / (uint32_t)C.s_pass;
+    const uint32_t m = C.pixel_list ? C.pixel_list[pl] : pl;
+    const uint32_t k = (uint32_t)C.sample_offset + (s % (uint32_t)C.s_pass);
+    f3 pos, dir;
+    camera_ray(cam, C.seed, m, k, pos, dir);
+    next.ray_o[ray_base + j] = make_float4(pos.x, pos.y, pos.z, 0.f);
+    next.ray_d[ray_base + j] = make_float4(dir.x, dir.y, dir.z, 0.f);
+#pragma unroll
+    for (uint32_t c = 0; c < 3; ++c) {
+        const uint32_t slot = C.free_slots[n_free_before - 1u - (3u * j + c)];
+        next.rec0[path_base + 3u * j + c] = make_uint4(s * 3u + c, ray_base + j, kFresh, 0u);
+        next.rec1[path_base + 3u * j + c] = make_float4(0.f, 0.f, 0.f, __uint_as_float(slot));
+    }
+    if (j == 0) C.counters->n_free = n_free_before - 3u * n_samples;
+}
+
+__global__ __launch_bounds__(kBlock) void k_generate_explicit(Wave next, uint32_t n) {
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    next.rec0[j] = make_uint4(j, j, kFresh, 0u);
+    next.rec1[j] = make_float4(0.f, 0.f, 0.f, __uint_as_float(j));
+}
+
+__global__ __launch_bounds__(kBlock) void k_camera_rays(CameraConst cam, uint32_t seed, uint32_t n, const uint32_t *pixel,
+                                                        const uint32_t *sample, float4 *o, float4 *d) {
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    f3 pos, dir;
+    camera_ray(cam, seed, pixel[j], sample[j], pos, dir);
+    o[j] = make_float4(pos.x, pos.y, pos.z, 0.f);
+    d[j] = make_float4(dir.x, dir.y, dir.z, 0.f);
+}
+
+__global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Counters *c, uint32_t pool) {
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j < pool) free_slots[j] = j;
+    if (j == 0) {
+        c->n_next = 0;
+        c->n_cont = 0;
+        c->n_free = pool;
+        c->pushes = 0;
+        c->overflow = 0;
+        c->finished = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Light sampling: Scene::sampleLight (Scene.cpp:23-37) -> MeshTriangle::Sample (Triangle.hpp:193-196)
+// -> BVHAccel::Sample/getSample (BVH.cpp:118-135) -> Triangle::Sample (Triangle.hpp:71-76).
+// u = {light choice, triangle pick, x, y}.  Returns false when no light was selected.
+// ------------------------------------------------------------------------------------------------
+MCPT_DI bool sample_light(const DevScene &S, const float u[4], f3 &x_l, f3 &n_l, f3 &emit, float &pdf) {
+    float area_sum = 0.f;
+    for (int k = 0; k < S.n_lights; ++k) area_sum += S.lights[k].area;
+    const float p = u[0] * area_sum;
+    area_sum = 0.f;
+    for (int k = 0; k < S.n_lights; ++k) {
+        const LightRec L = S.lights[k];
+        area_sum += L.area;
+        if (p <= area_sum) {
+            const MaterialRec &m = S.mats[L.mat];
+            if (L.kind == MCPT_OBJ_MESH) {
+                float pp = sqrtf(u[1]) * L.root_area;  // BVH.cpp:132 (the biased pick is reproduced)
+                int32_t ref = L.root;
+                while (ref >= 0) {  // BVH.cpp:118-129
+                    const LightNode N = S.light_nodes[ref];
+                    if (pp < N.left_area) {
+                        ref = N.left;
+                    } else {
+                        pp = pp - N.left_area;
+                        ref = N.right;
+                    }
+                }
+                const LightTri T = S.light_tris[~ref];
+                const float x = sqrtf(u[2]), y = u[3];  // Triangle.hpp:72
+                const f3 v0 = mk3(T.v0[0], T.v0[1], T.v0[2]), v1 = mk3(T.v1[0], T.v1[1], T.v1[2]), v2 = mk3(T.v2[0], T.v2[1], T.v2[2]);
+                x_l = (v0 * (1.0f - x) + v1 * (x * (1.0f - y))) + v2 * (x * y);
+                n_l = mk3(T.n[0], T.n[1], T.n[2]);
+                pdf = 1.0f / T.area;   // Triangle.hpp:75
+                pdf *= T.area;         // BVH.cpp:121
+                pdf /= L.root_area;    // BVH.cpp:134
+                emit = mk3(m.emit[0], m.emit[1], m.emit[2]);  // Triangle.hpp:195
+            } else {  // Sphere::Sample, Sphere.hpp:64-74 (leaves pos.emit untouched: zero here)
+                const SphereRec s = S.spheres[L.root];
+                const float theta = (float)(2.0 * (double)kPi * (double)u[2]), phi = kPi * u[3];
+                const f3 dir = mk3(cosf(phi), sinf(phi) * cosf(theta), sinf(phi) * sinf(theta));
+                x_l = mk3(s.c[0], s.c[1], s.c[2]) + dir * s.radius;
+                n_l = dir;
+                pdf = 1.0f / L.area;
+                emit = mk3(0.f, 0.f, 0.f);
+            }
+            return true;
+        }
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade: Scene::castRay (Scene.cpp:85-184) turned inside out.
+//
+// The recursion  L_d = clamp(0,15,l_dir_d) + clamp(0,5, L_{d+1} * f_d)  is not multiplicative (per-level
+// clamps, unclamped early returns), so a path cannot carry a scalar throughput.  Each level that
+// recurses pushes {clamp(0,15,l_dir), eval, |wo.n| (or -1 for Dirac), pdf} on a per-path clamp stack in
+// HBM; when the path ends the stack is unwound with exactly the reference's float expressions.
+// ------------------------------------------------------------------------------------------------
+MCPT_DI float unwind(const RenderConst &C, uint32_t slot, uint32_t depth, float X) {
+    for (int lvl = (int)depth - 1; lvl >= 0; --lvl) {
+        const float4 e = C.stack[(size_t)lvl * C.pool + slot];
+        float l_ind;
+        if (e.z < 0.f) l_ind = X * e.y * C.inv_rr;            // Scene.cpp:137-138,164-165 (isDirac)
+        else l_ind = X * e.y * e.z / e.w * C.inv_rr;           // Scene.cpp:140-143,167-170
+        X = e.x + clampf(0, 5, l_ind);                         // Scene.cpp:180-183
+    }
+    return X;
+}
+
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wave cur, Wave next, uint32_t n_cur) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i < n_cur;
+
+    uint32_t pid = 0, slot = 0, depth = 0, ray_idx = 0;
+    int ch = 0;
+    RngKey key{0, 0, 0, 0};
+    bool do_shade = false, finished = false, pushed = false, overflow = false;
+    float X = 0.f;
+    double hit_t = 0;
+    int32_t hit_prim = -1;
+
+    if (valid) {
+        const uint4 r0 = cur.rec0[i];
+        const float4 r1 = cur.rec1[i];
+        pid = r0.x;
+        ray_idx = r0.y;
+        depth = r0.z & 0xffffu;
+        const uint32_t flags = r0.z;
+        slot = __float_as_uint(r1.w);
+        path_key(C, pid, key, ch);
+
+        if (!(flags & kFresh)) {
+            // ---- resolve the pending vertex: Scene.cpp:114-119 (l_dir), 129-149 / 156-176 (l_ind)
+            float dl = 0.f;
+            for (int k = 0; k < C.n_dir; ++k) dl += cur.contrib[(size_t)i * C.n_dir + k];  // Scene.cpp:76 `l_dir +=`, in order
+            const float kr = __uint_as_float(r0.w);
+            const float l_dir = (flags & kInside) ? (float)((1. - (double)kr) * (double)dl) : kr * dl;
+            if (flags & kTerminate) {
+                X = l_dir;  // Scene.cpp:129-131,156-158: returned unclamped
+                finished = true;
+            } else {
+                const uint4 h = cur.hit[ray_idx];
+                hit_t = __longlong_as_double((long long)(((unsigned long long)h.y << 32) | h.x));
+                hit_prim = (int32_t)h.z;
+                bool surface = false;
+                if (hit_prim >= 0) {
+                    const int mat = hit_prim < S.n_tri ? S.tri_shade[hit_prim].mat : S.spheres[hit_prim - S.n_tri].mat;
+                    surface = !S.mats[mat].hasEmission;  // Scene.cpp:135,162
+                }
+                if (!surface) {
+                    const f3 wi = ld3(cur.ray_d[ray_idx]);
+                    const float env = comp(sample_env(S, wi), ch);  // Scene.cpp:145-149,172-176
+                    const float l_ind = env * r1.x * C.inv_rr;
+                    X = clampf(0, 15, l_dir) + clampf(0, 5, l_ind);
+                    finished = true;
+                } else if ((int)depth >= C.max_depth) {
+                    X = clampf(0, 15, l_dir);  // clamp stack exhausted: drop the indirect term, report it
+                    finished = true;
+                    overflow = true;
+                } else {
+                    C.stack[(size_t)depth * C.pool + slot] = make_float4(clampf(0, 15, l_dir), r1.x, r1.y, r1.z);
+                    depth += 1;
+                    pushed = true;
+                    do_shade = true;
+                }
+            }
+        } else {
+            const uint4 h = cur.hit[ray_idx];
+            hit_t = __longlong_as_double((long long)(((unsigned long long)h.y << 32) | h.x));
+            hit_prim = (int32_t)h.z;
+            if (hit_prim < 0) {
+                X = comp(sample_env(S, ld3(cur.ray_d[ray_idx])), ch);  // Scene.cpp:88-95
+                finished = true;
+            } else {
+                do_shade = true;  // the depth-0 emitter test needs the normal; done below
+            }
+        }
+    }
+
+    // ---- vertex set-up for lanes that shade
+    f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), p = mk3(0, 0, 0), n = mk3(0, 0, 1), wo = mk3(0, 0, -1);
+    f2 uv{0.f, 0.f};
+    int mat_id = 0;
+    if (do_shade) {
+        ro = ld3(cur.ray_o[ray_idx]);
+        rd = ld3(cur.ray_d[ray_idx]);
+        if (hit_prim < S.n_tri) {
+            const TriShade ts = S.tri_shade[hit_prim];
+            mat_id = ts.mat;
+            n = mk3(ts.n[0], ts.n[1], ts.n[2]);
+            p = ro + rd * (float)hit_t;  // Triangle.hpp:245 / Ray.hpp:21
+            if (S.mats[mat_id].textured) {  // Triangle.hpp:248: recompute the barycentrics of the recorded hit
+                double t, u, v;
+                const Ray rr = make_ray(ro, rd);
+                if (tri_hit(S.tri_geom[hit_prim], rr, t, u, v)) {
+                    const float a = (float)(1 - u - v), b = (float)u, c = (float)v;
+                    uv.x = a * ts.t0[0] + b * ts.t1[0] + c * ts.t2[0];
+                    uv.y = a * ts.t0[1] + b * ts.t1[1] + c * ts.t2[1];
+                }
+            }
+        } else {
+            const SphereRec s = S.spheres[hit_prim - S.n_tri];
+            mat_id = s.mat;
+            p = ro + rd * (float)hit_t;  // Sphere.hpp:40 (t0 is a float)
+            n = normalized(p - mk3(s.c[0], s.c[1], s.c[2]));
+        }
+        wo = -rd;
+        if (depth == 0 && S.mats[mat_id].hasEmission) {  // Scene.cpp:102-107
+            X = clampf(0, 1, S.mats[mat_id].emit[ch] * fabsf(dot(wo, n)));
+            finished = true;
+            do_shade = false;
+        }
+    }
+
+    // ---- finish: unwind the clamp stack, publish the path value, release the slot
+    if (finished) {
+        X = unwind(C, slot, depth, X);
+        C.result[pid] = X;
+    }
+    {
+        const uint32_t fi = wave_alloc(finished, &C.counters->n_free);
+        if (finished) C.free_slots[fi] = slot;
+        wave_count(finished, &C.counters->finished);
+        wave_count(pushed, &C.counters->pushes);
+        wave_count(overflow, &C.counters->overflow);
+    }
+
+    // ---- shade the new vertex: Scene.cpp:109-128,150-155
+    const MaterialRec m = S.mats[mat_id];
+    float u0[4] = {0.f, 0.f, 1.f, 0.f};
+    if (do_shade) rng_block(key, depth, 0u, u0);
+    const bool has_cont = do_shade && !(u0[2] >= C.rr_rate);  // Scene.cpp:121,129,156
+    const uint32_t j = wave_alloc(do_shade, &C.counters->n_next);
+    const uint32_t rj = wave_alloc(has_cont, &C.counters->n_cont);
+    if (!do_shade) return;
+
+    const f3 mfn = mat_sample(m, n, u0[0], u0[1]);   // Scene.cpp:109
+    const float kr = mat_fresnel(m, rd, mfn, ch);    // Scene.cpp:110
+    const f3 q = p + n * kEps;                       // Scene.cpp:114
+    const bool inside = dot(wo, n) < 0;              // Scene.cpp:115
+    next.sh_org[j] = make_float4(q.x, q.y, q.z, 0.f);
+    for (int k = 0; k < C.n_dir; ++k) {              // Scene::directLighting, Scene.cpp:56-82
+        float u[4];
+        rng_block(key, depth, 1u + (uint32_t)k, u);
+        f3 x_l = mk3(0, 0, 0), n_l = mk3(0, 0, 0), emit3 = mk3(0, 0, 0);
+        float pdf = 0.f;
+        float c = 0.f;
+        f3 ws = mk3(0, 0, 1);
+        float dist = 0.f;
+        if (sample_light(S, u, x_l, n_l, emit3, pdf)) {
+            const float emit = comp(emit3, ch);
+            ws = normalized(x_l - q);
+            dist = norm(x_l - q);
+            c = emit * mat_eval(m, ws, wo, n, ch, uv, !inside) * (dot(ws, n)) * dot(-ws, n_l) / (dist * dist) / pdf / C.n_dir;
+        }
+        next.sh_dir[(size_t)j * C.n_dir + k] = make_float4(ws.x, ws.y, ws.z, dist);
+        next.contrib[(size_t)j * C.n_dir + k] = c;
+    }
+
+    const bool isReflect = u0[3] < kr;  // Scene.cpp:123
+    f3 p2;
+    if (isReflect) p2 = (dot(wo, mfn) < 0) ? (p - n * kEps) : (p + n * kEps);  // Scene.cpp:124-128
+    else p2 = (dot(wo, mfn) < 0) ? (p + n * kEps) : (p - n * kEps);            // Scene.cpp:151-155
+
+    uint32_t flags = depth | (inside ? kInside : 0u);
+    float ev = 0.f, aw = 0.f, pd = 0.f;
+    if (has_cont) {
+        const f3 wi = isReflect ? mat_reflect(wo, mfn) : mat_refract(m, rd, mfn, ch);  // Scene.cpp:132,159
+        next.ray_o[rj] = make_float4(p2.x, p2.y, p2.z, 0.f);
+        next.ray_d[rj] = make_float4(wi.x, wi.y, wi.z, 0.f);
+        ev = mat_eval(m, wi, wo, n, ch, uv, isReflect);
+        if (m.isDirac) {
+            aw = -1.f;
+        } else {
+            aw = fabsf(dot(wo, n));
+            pd = mat_pdf(m, wi, wo, n, ch, isReflect);
+        }
+    } else {
+        flags |= kTerminate;
+    }
+    next.rec0[j] = make_uint4(pid, rj, flags, __float_as_uint(kr));
+    next.rec1[j] = make_float4(ev, aw, pd, __uint_as_float(slot));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_accumulate: framebuffer[m] += Vector3f(R,G,B)/spp, samples in order (Renderer.cpp:80).
+// One lane per (owned pixel, channel).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_accumulate(const float *__restrict__ result, const uint32_t *__restrict__ pixel_list,
+                                                       uint32_t n_pix, int32_t s_pass, float spp_total, float *__restrict__ fb) {
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= n_pix * 3u) return;
+    const uint32_t pl = g / 3u, c = g % 3u;
+    const uint32_t m = pixel_list ? pixel_list[pl] : pl;
+    float acc = fb[(size_t)m * 3 + c];
+    for (int k = 0; k < s_pass; ++k) acc += result[((size_t)pl * s_pass + k) * 3 + c] / spp_total;
+    fb[(size_t)m * 3 + c] = acc;
+}
+
+inline uint32_t blocks(uint32_t n) { return (n + kBlock - 1) / kBlock; }
+
+}  // namespace
+
+void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_free, dim3(blocks(pool)), dim3(kBlock), 0, s, free_slots, c, pool);
+}
+
+void launch_generate(const CameraConst &cam, const RenderConst &C, Wave next, uint32_t first_sample, uint32_t n_samples,
+                     uint32_t path_base, uint32_t ray_base, uint32_t n_free_before, hipStream_t s) {
+    if (n_samples == 0) return;
+    hipLaunchKernelGGL(k_generate, dim3(blocks(n_samples)), dim3(kBlock), 0, s, cam, C, next, first_sample, n_samples, path_base,
+                       ray_base, n_free_before);
+}
+
+void launch_generate_explicit(const RenderConst &C, Wave next, uint32_t n, hipStream_t s) {
+    (void)C;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_generate_explicit, dim3(blocks(n)), dim3(kBlock), 0, s, next, n);
+}
+
+void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const uint32_t *pixel, const uint32_t *sample,
+                        float4 *o, float4 *d, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_camera_rays, dim3(blocks(n)), dim3(kBlock), 0, s, cam, seed, n, pixel, sample, o, d);
+}
+
+// The LDS stack depth is picked from the scene's tree height (one pushed reference per level at most).
+template <bool SHADOW>
+static void launch_trace(const DevScene &S, uint32_t n, const float4 *ray_o, const float4 *ray_d, uint4 *hit, int32_t n_dir,
+                         const float4 *sh_org, const float4 *sh_dir, float *contrib, hipStream_t s) {
+    const dim3 g(blocks(n)), b(kBlock);
+    if (S.height <= 16) hipLaunchKernelGGL((k_trace<SHADOW, 16>), g, b, 0, s, S, n, ray_o, ray_d, hit, n_dir, sh_org, sh_dir, contrib);
+    else if (S.height <= 24) hipLaunchKernelGGL((k_trace<SHADOW, 24>), g, b, 0, s, S, n, ray_o, ray_d, hit, n_dir, sh_org, sh_dir, contrib);
+    else if (S.height <= 32) hipLaunchKernelGGL((k_trace<SHADOW, 32>), g, b, 0, s, S, n, ray_o, ray_d, hit, n_dir, sh_org, sh_dir, contrib);
+    else hipLaunchKernelGGL((k_trace<SHADOW, kMaxBvhHeight>), g, b, 0, s, S, n, ray_o, ray_d, hit, n_dir, sh_org, sh_dir, contrib);
+}
+
+void launch_trace_closest(const DevScene &S, uint32_t n, const float4 *ray_o, const float4 *ray_d, uint4 *hit, hipStream_t s) {
+    if (n == 0) return;
+    launch_trace<false>(S, n, ray_o, ray_d, hit, 1, nullptr, nullptr, nullptr, s);
+}
+
+void launch_trace_shadow(const DevScene &S, uint32_t n_rays, int32_t n_dir, const float4 *sh_org, const float4 *sh_dir,
+                         float *contrib, hipStream_t s) {
+    if (n_rays == 0) return;
+    launch_trace<true>(S, n_rays, nullptr, nullptr, nullptr, n_dir, sh_org, sh_dir, contrib, s);
+}
+
+void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, uint32_t n_cur, hipStream_t s) {
+    if (n_cur == 0) return;
+    hipLaunchKernelGGL(k_shade, dim3(blocks(n_cur)), dim3(kBlock), 0, s, S, C, cur, next, n_cur);
+}
+
+void launch_accumulate(const float *result, const uint32_t *pixel_list, uint32_t n_pix, int32_t s_pass, float spp_total,
+                       float *fb, hipStream_t s) {
+    if (n_pix == 0) return;
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks(n_pix * 3u)), dim3(kBlock), 0, s, result, pixel_list, n_pix, s_pass, spp_total, fb);
+}
+
+}  // namespace mcpt

@@ -1,0 +1,364 @@
+// Host-side scene construction: the data producer for the flat arrays the kernels traverse.
+//
+// Mirrors, as a builder of plain arrays instead of pointer objects:
+//   Triangle::Triangle ................ reference src/Triangle.hpp:50-56   (e1, e2, normal, area)
+//   MeshTriangle::MeshTriangle ........ src/Triangle.hpp:93-134            (bounding box, area sum, per-mesh BVH)
+//   Sphere::Sphere / getBounds ........ src/Sphere.hpp:20-21,58-63
+//   BVHAccel::recursiveBuild .......... src/BVH.cpp:27-93                  (median split on the centroid along the
+//                                                                          widest axis, one primitive per leaf, area sums)
+//   Scene::Add / buildBVH ............. src/Scene.hpp:104-109, Scene.cpp:14-17
+// The trees keep the reference's topology (so a primitive is tested exactly when the reference would
+// test it); std::stable_sort replaces the reference's unstable std::sort, whose tie order is unspecified.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+
+#include "mcpt_internal.h"
+
+namespace mcpt {
+namespace {
+
+struct V3 {
+    float x, y, z;
+};
+inline V3 ld(const float *p) { return {p[0], p[1], p[2]}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline float dot3(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }  // Eigen's 3-term redux order
+inline V3 cross3(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+struct Box {
+    V3 mn, mx;
+};
+inline Box box_empty() {  // Bounds3(), Bounds3.hpp:17-22
+    const float inf = std::numeric_limits<float>::infinity();
+    return {{inf, inf, inf}, {-inf, -inf, -inf}};
+}
+inline V3 vmin(V3 a, V3 b) { return {fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)}; }
+inline V3 vmax(V3 a, V3 b) { return {fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)}; }
+inline Box box_pp(V3 a, V3 b) { return {vmin(a, b), vmax(a, b)}; }                 // Bounds3.hpp:24-29
+inline Box box_union(Box a, Box b) { return {vmin(a.mn, b.mn), vmax(a.mx, b.mx)}; }  // Bounds3.hpp:110-115
+inline Box box_union(Box a, V3 p) { return {vmin(a.mn, p), vmax(a.mx, p)}; }         // Bounds3.hpp:117-122
+inline V3 centroid(Box b) {                                                          // Bounds3.hpp:47
+    return {0.5f * b.mn.x + 0.5f * b.mx.x, 0.5f * b.mn.y + 0.5f * b.mx.y, 0.5f * b.mn.z + 0.5f * b.mx.z};
+}
+inline int max_extent(Box b) {  // Bounds3.hpp:32-40
+    V3 d = b.mx - b.mn;
+    if (d.x > d.y && d.x > d.z) return 0;
+    if (d.y > d.z) return 1;
+    return 2;
+}
+inline float axis(V3 v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+struct BNode;
+struct BObj {
+    int prim;          // >= 0: global primitive id (triangle or sphere); -1: mesh
+    Box bounds;
+    float area;
+    BNode *mesh_root;  // mesh only
+};
+struct BNode {  // BVHBuildNode, BVH.hpp:53-69
+    Box bounds;
+    BNode *left = nullptr, *right = nullptr;
+    BObj *obj = nullptr;
+    float area = 0.f;
+};
+
+struct Arena {
+    std::vector<std::unique_ptr<BNode>> nodes;
+    BNode *make() {
+        nodes.emplace_back(new BNode());
+        return nodes.back().get();
+    }
+};
+
+BNode *recursive_build(Arena &A, std::vector<BObj *> objs) {  // BVH.cpp:27-93
+    BNode *node = A.make();
+    node->bounds = box_empty();
+    if (objs.size() == 1) {
+        node->bounds = objs[0]->bounds;
+        node->obj = objs[0];
+        node->area = objs[0]->area;
+        return node;
+    }
+    if (objs.size() == 2) {
+        node->left = recursive_build(A, {objs[0]});
+        node->right = recursive_build(A, {objs[1]});
+        node->bounds = box_union(node->left->bounds, node->right->bounds);
+        node->area = node->left->area + node->right->area;
+        return node;
+    }
+    Box cb = box_empty();
+    for (BObj *o : objs) cb = box_union(cb, centroid(o->bounds));
+    const int dim = max_extent(cb);
+    std::stable_sort(objs.begin(), objs.end(),
+                     [dim](const BObj *a, const BObj *b) { return axis(centroid(a->bounds), dim) < axis(centroid(b->bounds), dim); });
+    const size_t mid = objs.size() / 2;
+    node->left = recursive_build(A, std::vector<BObj *>(objs.begin(), objs.begin() + mid));
+    node->right = recursive_build(A, std::vector<BObj *>(objs.begin() + mid, objs.end()));
+    node->bounds = box_union(node->left->bounds, node->right->bounds);
+    node->area = node->left->area + node->right->area;
+    return node;
+}
+
+inline void store3(float *d, V3 v) {
+    d[0] = v.x;
+    d[1] = v.y;
+    d[2] = v.z;
+}
+
+struct Flattener {
+    HostScene &hs;
+    int height = 0;
+
+    // Returns the child reference for `n` (inner node index, or ~primitive for a leaf).
+    int32_t flatten(const BNode *n, int depth) {
+        if (n->obj) {
+            if (n->obj->prim >= 0) {
+                height = std::max(height, depth);
+                return ~n->obj->prim;
+            }
+            return flatten(n->obj->mesh_root, depth);  // MeshTriangle::getIntersection -> its own BVH, Triangle.hpp:183-191
+        }
+        const int32_t idx = (int32_t)hs.nodes.size();
+        hs.nodes.emplace_back();
+        const int32_t l = flatten(n->left, depth + 1);
+        const int32_t r = flatten(n->right, depth + 1);
+        Node &N = hs.nodes[idx];
+        std::memset(&N, 0, sizeof N);
+        store3(N.lmin, n->left->bounds.mn);
+        store3(N.lmax, n->left->bounds.mx);
+        store3(N.rmin, n->right->bounds.mn);
+        store3(N.rmax, n->right->bounds.mx);
+        N.left = l;
+        N.right = r;
+        return idx;
+    }
+
+    // Area tree of a light mesh for BVHAccel::getSample (BVH.cpp:118-129).
+    int32_t flatten_light(const BNode *n, int depth, int &max_depth, const mcpt_scene_desc &d) {
+        max_depth = std::max(max_depth, depth);
+        if (n->left == nullptr || n->right == nullptr) {
+            const int ti = n->obj->prim;
+            LightTri T;
+            std::memset(&T, 0, sizeof T);
+            for (int k = 0; k < 3; ++k) {
+                T.v0[k] = d.triangles[ti].v0[k];
+                T.v1[k] = d.triangles[ti].v1[k];
+                T.v2[k] = d.triangles[ti].v2[k];
+                T.n[k] = hs.tri_shade[ti].n[k];
+            }
+            T.area = n->area;  // leaf BVHBuildNode::area == Triangle::area (BVH.cpp:38)
+            hs.light_tris.push_back(T);
+            return ~(int32_t)(hs.light_tris.size() - 1);
+        }
+        const int32_t idx = (int32_t)hs.light_nodes.size();
+        hs.light_nodes.emplace_back();
+        const int32_t l = flatten_light(n->left, depth + 1, max_depth, d);
+        const int32_t r = flatten_light(n->right, depth + 1, max_depth, d);
+        LightNode &L = hs.light_nodes[idx];
+        L.left_area = n->left->area;
+        L.left = l;
+        L.right = r;
+        L.area = n->area;
+        return idx;
+    }
+};
+
+}  // namespace
+
+int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) {
+    *err = "";
+    if (d.n_objects <= 0 || !d.objects || d.n_materials <= 0 || !d.materials || d.n_triangles < 0 ||
+        (d.n_triangles > 0 && !d.triangles)) {
+        *err = "scene description: empty or null arrays";
+        return MCPT_ERR_ARG;
+    }
+    hs.n_triangles = d.n_triangles;
+    hs.n_objects = d.n_objects;
+
+    // materials, Material.hpp:245-262
+    hs.materials.resize(d.n_materials);
+    for (int i = 0; i < d.n_materials; ++i) {
+        const mcpt_material &m = d.materials[i];
+        if (m.type < 0 || m.type > 3) {
+            *err = "material type out of range";
+            return MCPT_ERR_ARG;
+        }
+        MaterialRec &r = hs.materials[i];
+        std::memset(&r, 0, sizeof r);
+        r.type = m.type;
+        r.textured = m.textured ? 1 : 0;
+        r.isDirac = (m.type == MCPT_SMOOTH_CONDUCTOR || m.type == MCPT_SMOOTH_DIELECTRIC);
+        r.roughness = m.roughness;
+        r.iorA = m.iorA;
+        r.iorB = m.iorB;
+        for (int k = 0; k < 3; ++k) {
+            r.refl[k] = m.base_reflectance[k];
+            r.emit[k] = m.emission[k];
+        }
+        const V3 e = ld(m.emission);
+        r.hasEmission = sqrtf(dot3(e, e)) > kEps;  // Material::hasEmission, Material.hpp:262
+    }
+
+    hs.tri_geom.resize(d.n_triangles);
+    hs.tri_shade.resize(d.n_triangles);
+    hs.tri_area.resize(d.n_triangles);
+    hs.spheres.resize(d.n_objects);
+    std::memset(hs.spheres.data(), 0, hs.spheres.size() * sizeof(SphereRec));
+
+    Arena arena;
+    std::vector<BObj> tri_objs(d.n_triangles);
+    std::vector<BObj> top_objs(d.n_objects);
+    std::vector<uint8_t> tri_seen(d.n_triangles, 0);
+    int light_depth = 0;
+
+    for (int oi = 0; oi < d.n_objects; ++oi) {
+        const mcpt_object &o = d.objects[oi];
+        if (o.material < 0 || o.material >= d.n_materials) {
+            *err = "object material index out of range";
+            return MCPT_ERR_ARG;
+        }
+        BObj &B = top_objs[oi];
+        if (o.kind == MCPT_OBJ_SPHERE) {  // Sphere.hpp:20-21,58-63
+            SphereRec &s = hs.spheres[oi];
+            for (int k = 0; k < 3; ++k) s.c[k] = o.center[k];
+            s.radius = o.radius;
+            s.radius2 = o.radius * o.radius;
+            s.mat = o.material;
+            B.prim = d.n_triangles + oi;
+            const V3 c = ld(o.center);
+            B.bounds = box_pp({c.x - o.radius, c.y - o.radius, c.z - o.radius}, {c.x + o.radius, c.y + o.radius, c.z + o.radius});
+            B.area = 4 * 3.141592653589793f * o.radius * o.radius;
+            B.mesh_root = nullptr;
+        } else if (o.kind == MCPT_OBJ_MESH) {  // Triangle.hpp:93-134
+            if (o.first_tri < 0 || o.n_tri <= 0 || o.first_tri > d.n_triangles - o.n_tri) {
+                *err = "mesh triangle range out of bounds";
+                return MCPT_ERR_ARG;
+            }
+            const float inf = std::numeric_limits<float>::infinity();
+            V3 mn{inf, inf, inf}, mx{-inf, -inf, -inf};
+            float area = 0.f;
+            std::vector<BObj *> ptrs;
+            ptrs.reserve(o.n_tri);
+            for (int k = 0; k < o.n_tri; ++k) {
+                const int ti = o.first_tri + k;
+                if (tri_seen[ti]) {
+                    *err = "triangle ranges of two meshes overlap";
+                    return MCPT_ERR_ARG;
+                }
+                tri_seen[ti] = 1;
+                const mcpt_triangle &t = d.triangles[ti];
+                const V3 v0 = ld(t.v0), v1 = ld(t.v1), v2 = ld(t.v2);
+                const V3 e1 = v1 - v0, e2 = v2 - v0;  // Triangle.hpp:52-55
+                const V3 c = cross3(e1, e2);
+                const float z = dot3(c, c);
+                const V3 n = z > 0.f ? V3{c.x / sqrtf(z), c.y / sqrtf(z), c.z / sqrtf(z)} : c;
+                const float a = sqrtf(dot3(c, c)) * 0.5f;
+                TriGeom &g = hs.tri_geom[ti];
+                std::memset(&g, 0, sizeof g);
+                store3(g.v0, v0);
+                g.e1x = e1.x;
+                g.e1yz[0] = e1.y;
+                g.e1yz[1] = e1.z;
+                g.e2xy[0] = e2.x;
+                g.e2xy[1] = e2.y;
+                g.e2z = e2.z;
+                TriShade &s = hs.tri_shade[ti];
+                std::memset(&s, 0, sizeof s);
+                store3(s.n, n);
+                s.mat = o.material;
+                for (int q = 0; q < 2; ++q) {
+                    s.t0[q] = t.t0[q];
+                    s.t1[q] = t.t1[q];
+                    s.t2[q] = t.t2[q];
+                }
+                hs.tri_area[ti] = a;
+                BObj &T = tri_objs[ti];
+                T.prim = ti;
+                T.bounds = box_union(box_pp(v0, v1), v2);  // Triangle::getBounds, Triangle.hpp:220
+                T.area = a;
+                T.mesh_root = nullptr;
+                ptrs.push_back(&T);
+                const V3 vs[3] = {v0, v1, v2};
+                for (const V3 &v : vs) {  // cwiseMin/cwiseMax, Triangle.hpp:108-109
+                    mn = {std::min(mn.x, v.x), std::min(mn.y, v.y), std::min(mn.z, v.z)};
+                    mx = {std::max(mx.x, v.x), std::max(mx.y, v.y), std::max(mx.z, v.z)};
+                }
+                area += a;  // Triangle.hpp:129-132
+            }
+            B.prim = -1;
+            B.bounds = box_pp(mn, mx);
+            B.area = area;
+            B.mesh_root = recursive_build(arena, ptrs);
+        } else {
+            *err = "object kind out of range";
+            return MCPT_ERR_ARG;
+        }
+    }
+
+    std::vector<BObj *> tops;
+    for (BObj &b : top_objs) tops.push_back(&b);
+    const BNode *root = recursive_build(arena, tops);  // Scene::buildBVH, Scene.cpp:14-17
+
+    Flattener F{hs};
+    hs.nodes.reserve((size_t)d.n_triangles + d.n_objects + 8);
+    hs.root = F.flatten(root, 1);
+    hs.height = F.height;
+    store3(hs.root_min, root->bounds.mn);
+    store3(hs.root_max, root->bounds.mx);
+    if (hs.height > kMaxBvhHeight) {
+        *err = "BVH height exceeds the traversal stack (kMaxBvhHeight)";
+        return MCPT_ERR_LIMIT;
+    }
+    if (hs.nodes.empty()) {  // keep the device array non-empty
+        hs.nodes.emplace_back();
+        std::memset(&hs.nodes[0], 0, sizeof(Node));
+        hs.nodes[0].left = hs.nodes[0].right = kNoChild;
+    }
+
+    // light table, Scene.hpp:106-108 (insertion order)
+    hs.light_area_sum = 0.f;
+    for (int oi = 0; oi < d.n_objects; ++oi) {
+        const mcpt_object &o = d.objects[oi];
+        if (!hs.materials[o.material].hasEmission) continue;
+        LightRec L;
+        std::memset(&L, 0, sizeof L);
+        L.area = top_objs[oi].area;
+        L.kind = o.kind;
+        L.mat = o.material;
+        if (o.kind == MCPT_OBJ_MESH) {
+            const BNode *mr = top_objs[oi].mesh_root;
+            L.root_area = mr->area;
+            int depth = 0;
+            L.root = F.flatten_light(mr, 1, depth, d);
+            light_depth = std::max(light_depth, depth);
+        } else {
+            L.root = oi;
+            L.root_area = L.area;
+        }
+        hs.lights.push_back(L);
+        hs.light_area_sum += L.area;  // Scene.cpp:24-27
+    }
+    if (light_depth > kMaxLightTreeDepth) {
+        *err = "light mesh tree too deep";
+        return MCPT_ERR_LIMIT;
+    }
+    if (hs.light_nodes.empty()) hs.light_nodes.push_back(LightNode{0.f, kNoChild, kNoChild, 0.f});
+    if (hs.light_tris.empty()) {
+        LightTri T;
+        std::memset(&T, 0, sizeof T);
+        hs.light_tris.push_back(T);
+    }
+
+    for (int k = 0; k < 3; ++k) hs.background[k] = d.background[k];
+    if (d.env_w > 0 && d.env_h > 0 && d.env_pixels) {
+        hs.env_w = d.env_w;
+        hs.env_h = d.env_h;
+        hs.env.assign(d.env_pixels, d.env_pixels + (size_t)d.env_w * d.env_h * 3);
+    }
+    return MCPT_OK;
+}
+
+}  // namespace mcpt

@@ -1,0 +1,195 @@
+"""ctypes binding to libmcpt_hip.so (the C ABI of include/mcpt.h) and a Python mirror of the reference's
+`Renderer` seam: `HipScene` plays Scene (after Add/buildBVH), `HipScene.render` plays Renderer::Render
+(reference src/Renderer.hpp:16-22, src/Scene.hpp:104-131).
+
+There is no CPU fallback here: if the HIP library is missing or no GPU is usable, every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmcpt_hip.so")
+
+EXPORTS = ["mcpt_scene_create", "mcpt_scene_destroy", "mcpt_render", "mcpt_render_device", "mcpt_intersect",
+           "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_last_error", "mcpt_version"]
+
+
+class McptError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mcpt error %d: %s" % (code, msg))
+        self.code = code
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_objects", C.c_int32), ("n_triangles", C.c_int32), ("n_materials", C.c_int32),
+                ("env_w", C.c_int32), ("env_h", C.c_int32), ("background", C.c_float * 3),
+                ("objects", C.c_void_p), ("triangles", C.c_void_p), ("materials", C.c_void_p), ("env_pixels", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("spp", C.c_int32), ("spp_total", C.c_int32), ("sample_offset", C.c_int32), ("rr_rate", C.c_float),
+                ("n_dir_sample", C.c_int32), ("enable_shadow", C.c_int32), ("seed", C.c_uint32), ("accumulate", C.c_int32),
+                ("tile_size", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32), ("spp_per_pass", C.c_int32),
+                ("pool_paths", C.c_int32), ("max_depth", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("paths", C.c_uint64), ("vertices", C.c_uint64), ("shaded", C.c_uint64),
+                ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("ref_scene_rays", C.c_uint64),
+                ("iterations", C.c_uint64), ("overflow_paths", C.c_uint64), ("ms_total", C.c_double),
+                ("ms_trace_closest", C.c_double), ("ms_trace_shadow", C.c_double), ("ms_shade", C.c_double),
+                ("ms_generate", C.c_double), ("ms_resolve", C.c_double),
+                ("n_trace_closest", C.c_uint64), ("n_trace_shadow", C.c_uint64), ("n_shade", C.c_uint64),
+                ("n_generate", C.c_uint64), ("n_resolve", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("bvh_height", C.c_int32), ("n_lights", C.c_int32), ("n_prims", C.c_int32),
+                ("scene_bytes", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libmcpt_hip.so; raises if it has not been built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError("%s is missing: build it with `python __graft_entry__.py` (hipcc, gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.mcpt_last_error.restype = C.c_char_p
+        L.mcpt_version.restype = C.c_char_p
+        L.mcpt_scene_create.restype = C.c_int
+        L.mcpt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.mcpt_scene_destroy.restype = None
+        L.mcpt_scene_destroy.argtypes = [C.c_void_p]
+        L.mcpt_scene_get_info.restype = C.c_int
+        L.mcpt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
+        L.mcpt_render.restype = C.c_int
+        L.mcpt_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]
+        L.mcpt_render_device.restype = C.c_int
+        L.mcpt_render_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.mcpt_intersect.restype = C.c_int
+        L.mcpt_intersect.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcpt_cast_rays.restype = C.c_int
+        L.mcpt_cast_rays.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int64] + [C.c_void_p] * 6
+        L.mcpt_camera_rays.restype = C.c_int
+        L.mcpt_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64] + [C.c_void_p] * 4
+        _lib = L
+    return _lib
+
+
+def _check(rc, allow=()):
+    if rc != 0 and rc not in allow:
+        raise McptError(rc, lib().mcpt_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class HipScene:
+    """A scene resident in the HBM of one GPU (mcpt_scene_create)."""
+
+    def __init__(self, sd, device=-1):
+        self.sd = sd
+        self._tri = np.ascontiguousarray(sd.triangles)
+        self._mat = np.ascontiguousarray(sd.materials)
+        self._obj = np.ascontiguousarray(sd.objects)
+        d = SceneDesc()
+        d.n_objects, d.n_triangles, d.n_materials = len(self._obj), len(self._tri), len(self._mat)
+        d.background = (C.c_float * 3)(*[float(x) for x in sd.background])
+        d.objects, d.triangles, d.materials = _ptr(self._obj), _ptr(self._tri), _ptr(self._mat)
+        if sd.env_pixels is not None:
+            self._env = np.ascontiguousarray(sd.env_pixels, dtype=np.float32)
+            d.env_h, d.env_w = self._env.shape[:2]
+            d.env_pixels = _ptr(self._env)
+        h = C.c_void_p()
+        self.h = None
+        _check(lib().mcpt_scene_create(C.byref(d), int(device), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mcpt_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        i = SceneInfo()
+        _check(lib().mcpt_scene_get_info(self.h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in i._fields_}
+
+    def params(self, spp=None, seed=1, spp_total=0, sample_offset=0, accumulate=0, tile_size=32, rank=0, nranks=1,
+               n_dir_sample=None, spp_per_pass=0, pool_paths=0, max_depth=0):
+        sd = self.sd
+        return Params(spp=int(spp if spp is not None else sd.spp), spp_total=int(spp_total), sample_offset=int(sample_offset),
+                      rr_rate=float(sd.rr_rate), n_dir_sample=int(n_dir_sample if n_dir_sample is not None else sd.n_dir_sample),
+                      enable_shadow=int(sd.enable_shadow), seed=int(seed), accumulate=int(accumulate), tile_size=int(tile_size),
+                      rank=int(rank), nranks=int(nranks), spp_per_pass=int(spp_per_pass), pool_paths=int(pool_paths),
+                      max_depth=int(max_depth))
+
+    def render(self, camera=None, fb=None, **kw):
+        """Renderer::Render up to the float framebuffer: returns (fb[H,W,3] float32, Stats)."""
+        cam = np.ascontiguousarray(camera if camera is not None else self.sd.camera)
+        W, H = int(cam["width"]), int(cam["height"])
+        if fb is None:
+            fb = np.zeros((H, W, 3), dtype=np.float32)
+        p = self.params(**kw)
+        st = Stats()
+        _check(lib().mcpt_render(self.h, _ptr(cam), C.byref(p), _ptr(fb), C.byref(st)))
+        return fb, st
+
+    def render_device(self, fb_ptr, stream_ptr=0, camera=None, **kw):
+        """Same, into a device framebuffer (W*H*3 floats at fb_ptr) on the given hipStream_t handle."""
+        cam = np.ascontiguousarray(camera if camera is not None else self.sd.camera)
+        p = self.params(**kw)
+        st = Stats()
+        _check(lib().mcpt_render_device(self.h, _ptr(cam), C.byref(p), C.c_void_p(int(fb_ptr)), C.c_void_p(int(stream_ptr)),
+                                        C.byref(st)))
+        return st
+
+    def intersect(self, origins, dirs):
+        o = np.ascontiguousarray(origins, dtype=np.float32)
+        d = np.ascontiguousarray(dirs, dtype=np.float32)
+        n = len(o)
+        t = np.zeros(n, dtype=np.float64)
+        prim = np.zeros(n, dtype=np.int32)
+        _check(lib().mcpt_intersect(self.h, n, _ptr(o), _ptr(d), _ptr(t), _ptr(prim)))
+        return t, prim
+
+    def cast_rays(self, origins, dirs, pixel, sample, channel, **kw):
+        o = np.ascontiguousarray(origins, dtype=np.float32)
+        d = np.ascontiguousarray(dirs, dtype=np.float32)
+        n = len(o)
+        px = np.ascontiguousarray(pixel, dtype=np.uint32)
+        sm = np.ascontiguousarray(sample, dtype=np.uint32)
+        ch = np.ascontiguousarray(channel, dtype=np.int32)
+        out = np.zeros(n, dtype=np.float32)
+        p = self.params(**kw)
+        _check(lib().mcpt_cast_rays(self.h, C.byref(p), n, _ptr(o), _ptr(d), _ptr(px), _ptr(sm), _ptr(ch), _ptr(out)))
+        return out
+
+    def camera_rays(self, pixels, samples, seed=1, camera=None):
+        cam = np.ascontiguousarray(camera if camera is not None else self.sd.camera)
+        px = np.ascontiguousarray(pixels, dtype=np.uint32)
+        sm = np.ascontiguousarray(samples, dtype=np.uint32)
+        n = len(px)
+        o = np.zeros((n, 3), dtype=np.float32)
+        d = np.zeros((n, 3), dtype=np.float32)
+        _check(lib().mcpt_camera_rays(self.h, _ptr(cam), int(seed), n, _ptr(px), _ptr(sm), _ptr(o), _ptr(d)))
+        return o, d

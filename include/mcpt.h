@@ -1,0 +1,166 @@
+/*
+ * mcpt.h -- C ABI of the MI355X-native path-tracing hot path (libmcpt_hip.so).
+ *
+ * The reference (a single C++ executable) has no plugin/FFI interface; its only seam around the hot
+ * path is the C++ call  Renderer::Render(const Scene&)  (src/Renderer.hpp:16, called once at
+ * src/main.cpp:333) configured through Renderer::setSpp (Renderer.hpp:18) and the Scene setters
+ * (Scene.hpp:104-119).  The entry points below are exactly what a binding for that seam needs; each
+ * one names the reference interface it replaces.  Plain pointers and sizes only: no C++ or torch types.
+ *
+ * All functions return 0 on success or an mcpt_status code; mcpt_last_error() returns a thread-local
+ * description of the last failure.  A scene handle may be used by one host thread at a time.
+ * The library never falls back to a CPU path: without a usable HIP device every call fails with
+ * MCPT_ERR_HIP.
+ */
+#ifndef MCPT_H
+#define MCPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MCPT_OK = 0,
+    MCPT_ERR_ARG = 1,      /* bad argument / inconsistent description */
+    MCPT_ERR_HIP = 2,      /* HIP runtime error (no device, launch failure, ...) */
+    MCPT_ERR_OOM = 3,      /* host or device allocation failed */
+    MCPT_ERR_LIMIT = 4,    /* a compiled-in limit was exceeded (BVH depth, light-tree depth) */
+    MCPT_ERR_OVERFLOW = 5  /* a path outran the clamp stack (params.max_depth); frame is still returned */
+} mcpt_status;
+
+/* MaterialType, src/Material.hpp:13-18 */
+enum { MCPT_SMOOTH_CONDUCTOR = 0, MCPT_ROUGH_CONDUCTOR = 1, MCPT_SMOOTH_DIELECTRIC = 2, MCPT_ROUGH_DIELECTRIC = 3 };
+enum { MCPT_OBJ_MESH = 0, MCPT_OBJ_SPHERE = 1 };
+
+/* One Triangle of a MeshTriangle (src/Triangle.hpp:41-56, 99-124): world-space vertices, texture coords. */
+typedef struct {
+    float v0[3], v1[3], v2[3];
+    float t0[2], t1[2], t2[2];
+} mcpt_triangle; /* 60 bytes */
+
+/* src/Material.hpp:157-167 (+ ctor defaults :245-257): the fields the hot path reads. */
+typedef struct {
+    int32_t type;
+    int32_t textured; /* checkerboard reflectance, Material.hpp:134-151 */
+    float roughness, iorA, iorB;
+    float base_reflectance[3];
+    float emission[3];
+} mcpt_material; /* 44 bytes */
+
+/* One Scene::Add()-ed Object (src/Scene.hpp:104-109): a MeshTriangle or a Sphere (src/Sphere.hpp:10-21). */
+typedef struct {
+    int32_t kind;      /* MCPT_OBJ_MESH | MCPT_OBJ_SPHERE */
+    int32_t material;  /* index into materials */
+    int32_t first_tri; /* mesh: first triangle in `triangles`, file order */
+    int32_t n_tri;     /* mesh: triangle count */
+    float center[3];   /* sphere */
+    float radius;      /* sphere */
+} mcpt_object; /* 32 bytes */
+
+/* Everything Scene holds once main() has assembled it (src/Scene.hpp:32-38,147-149). Borrowed pointers:
+ * the library copies what it needs into HBM; the caller keeps ownership. */
+typedef struct {
+    int32_t n_objects;
+    int32_t n_triangles;
+    int32_t n_materials;
+    int32_t env_w, env_h;          /* 0,0 => constant background colour (Scene.hpp:33,61-63) */
+    float background[3];
+    const mcpt_object *objects;    /* in Scene::Add order */
+    const mcpt_triangle *triangles;
+    const mcpt_material *materials;
+    const float *env_pixels;       /* env_w*env_h*3 floats in [0,1], row-major (Scene.hpp:48-56) */
+} mcpt_scene_desc;
+
+/* src/Camera.hpp:6-26 after lookAt(). */
+typedef struct {
+    int32_t width, height;
+    float fov;            /* degrees */
+    float position[3];
+    float orientation[9]; /* row-major 3x3, columns = left, up, forward (Camera.hpp:21-23) */
+    int32_t use_dof;
+    float focal_distance, aperture_radius;
+} mcpt_camera; /* 72 bytes */
+
+/* Renderer::spp (Renderer.hpp:18,22) + the private Scene knobs (Scene.hpp:25-28,110-119) + launch shape. */
+typedef struct {
+    int32_t spp;           /* samples per pixel rendered by this call */
+    int32_t spp_total;     /* divisor of `framebuffer += rgb/spp` (Renderer.cpp:80); 0 => spp */
+    int32_t sample_offset; /* index of this call's first sample (progressive accumulation); RNG key uses offset+k */
+    float rr_rate;         /* caller applies min(rr, 0.99f) as Scene::setRrRate does */
+    int32_t n_dir_sample;  /* Scene::n_dir_sample (the reference always runs 4) */
+    int32_t enable_shadow;
+    uint32_t seed;
+    int32_t accumulate;    /* 0: framebuffer is overwritten for owned pixels; 1: added to */
+    /* pixel-tile partition (multi-GPU): pixel (i,j) is owned iff ((j/tile)*ceil(W/tile) + i/tile) % nranks == rank */
+    int32_t tile_size, rank, nranks;
+    /* launch shape; 0 => library default */
+    int32_t spp_per_pass;  /* samples per pixel in flight per pass (sizes the per-pass result buffer) */
+    int32_t pool_paths;    /* wavefront pool capacity in channel-paths */
+    int32_t max_depth;     /* clamp-stack levels per path; 0 => derived from rr_rate (P[deeper] < 1e-12) */
+} mcpt_params;
+
+typedef struct {
+    uint64_t samples;       /* camera samples */
+    uint64_t paths;         /* channel paths = 3 * samples */
+    uint64_t vertices;      /* Scene::castRay invocations the reference would execute (Scene.cpp:85) */
+    uint64_t shaded;        /* vertices that reached Material::sample (Scene.cpp:109) */
+    uint64_t closest_rays;  /* closest-hit rays actually traced (primary once per sample + continuations) */
+    uint64_t shadow_rays;   /* shadow rays actually traced */
+    uint64_t ref_scene_rays;/* Scene::intersect calls the reference would make for the same work */
+    uint64_t iterations;    /* wavefront iterations */
+    uint64_t overflow_paths;/* paths cut by max_depth */
+    double ms_total;        /* wall time of the call, host clock */
+    double ms_trace_closest, ms_trace_shadow, ms_shade, ms_generate, ms_resolve; /* HIP-event sums per kernel class */
+    uint64_t n_trace_closest, n_trace_shadow, n_shade, n_generate, n_resolve;    /* launches per kernel class */
+} mcpt_stats;
+
+typedef struct mcpt_scene mcpt_scene;
+
+/* Replaces Scene::Add + Scene::buildBVH (Scene.hpp:104-109, Scene.cpp:14-17) and MeshTriangle's per-mesh
+ * BVHAccel (Triangle.hpp:128-134, BVH.cpp:27-93): builds the flattened BVH and uploads the scene to HBM
+ * of the current (or `device`) GPU. */
+int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out);
+void mcpt_scene_destroy(mcpt_scene *scene);
+
+/* Replaces the pixel/spp loop of Renderer::Render (Renderer.cpp:21-91): fb_host = W*H*3 floats,
+ * row-major m = j*W + i, linear radiance averaged over spp -- what `framebuffer` holds at Renderer.cpp:91.
+ * Blocking.  Tone map and PNG output (Renderer.cpp:95-109) stay with the caller. */
+int mcpt_render(mcpt_scene *scene, const mcpt_camera *camera, const mcpt_params *params, float *fb_host,
+                mcpt_stats *stats);
+
+/* Same, with the framebuffer left in HBM (fb_device: W*H*3 floats on the scene's device) and all work issued
+ * on `hip_stream` (a hipStream_t; NULL = default stream).  Used when the caller reduces frames with RCCL. */
+int mcpt_render_device(mcpt_scene *scene, const mcpt_camera *camera, const mcpt_params *params, float *fb_device,
+                       void *hip_stream, mcpt_stats *stats);
+
+/* Replaces Scene::intersect (Scene.hpp:128, Scene.cpp:19-21) for a list of rays (host pointers; n*3 floats each).
+ * out_t: hit distance as the reference's double Intersection::distance (DBL_MAX on a miss);
+ * out_prim: global primitive id (triangle index, or n_triangles + object index for a sphere; -1 on a miss). */
+int mcpt_intersect(mcpt_scene *scene, int64_t n, const float *origins, const float *dirs, double *out_t,
+                   int32_t *out_prim);
+
+/* Replaces Scene::castRay(ray, 0, channel) (Scene.hpp:131, Scene.cpp:85-184) for a list of rays (host pointers).
+ * The RNG of ray i is keyed by (params->seed, pixel[i], sample[i], channel[i]). */
+int mcpt_cast_rays(mcpt_scene *scene, const mcpt_params *params, int64_t n, const float *origins, const float *dirs,
+                   const uint32_t *pixel, const uint32_t *sample, const int32_t *channel, float *out);
+
+/* Camera ray generation of Renderer.cpp:44-76 for (pixel m, sample k) pairs (host pointers); origins/dirs: n*3 floats. */
+int mcpt_camera_rays(mcpt_scene *scene, const mcpt_camera *camera, uint32_t seed, int64_t n, const uint32_t *pixel,
+                     const uint32_t *sample, float *origins, float *dirs);
+
+/* Scene statistics for reporting (BVH nodes, tree height, bytes resident in HBM). */
+typedef struct {
+    int32_t n_nodes, bvh_height, n_lights, n_prims;
+    uint64_t scene_bytes;
+} mcpt_scene_info;
+int mcpt_scene_get_info(const mcpt_scene *scene, mcpt_scene_info *info);
+
+const char *mcpt_last_error(void);
+const char *mcpt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCPT_H */
