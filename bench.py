@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+Metric (BASELINE.json): Msamples/s = width*height*spp / seconds / 1e6 on the chess scene at 1920x1080
+(BASELINE config 4: conf.json as shipped, DoF on, RR 0.4, constant sky colour because sky.png is missing,
+n_dir_sample = 4 as the reference executes; pass --n-dir 32 for the README's label).
+
+A "step" is one pass of --spp-per-step samples per pixel over the whole frame, accumulated into the
+device framebuffer (progressive rendering: K steps = K*spp_per_step spp of the same frame).  The scene
+is resident in HBM before the timed region.  With N ranks the frame is partitioned into interleaved
+32x32 pixel tiles (strong scaling: the frame is fixed), every rank renders its tiles, and the timed
+region ends with one RCCL reduce of the framebuffer to rank 0 (torch.distributed, backend nccl).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+BYTES_PER_RAY = 96     # ray record 32 B written + 32 B read, hit record 16 B written + 16 B read
+BYTES_PER_VERTEX = 96  # path state 48 B read + 48 B written
+BYTES_PER_SAMPLE = 12  # framebuffer contribution
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--n-dir", type=int, default=4)
+    ap.add_argument("--scene", default="chess", choices=["chess", "cornell_demo", "cornell_rc"])
+    ap.add_argument("--pool-paths", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=2, help="spp of the bounded CPU-baseline sample (full frame)")
+    ap.add_argument("--no-psnr", action="store_true")
+    ap.add_argument("--save-png", default="")
+    return ap.parse_args()
+
+
+def make_scene(pkg, args):
+    if args.scene == "chess":
+        return pkg.scenes.chess_scene(width=args.width, height=args.height, spp=args.spp_per_step)
+    if args.scene == "cornell_demo":
+        return pkg.scenes.cornell_demo(args.width, args.height, args.spp_per_step)
+    return pkg.scenes.cornell_rc(args.width, args.height, args.spp_per_step)
+
+
+def load_traffic():
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc pass (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse_args()
+    import torch
+    import mcpt_loader
+    pkg = mcpt_loader.load()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed and world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    sd = make_scene(pkg, args)
+    W, H = args.width, args.height
+    hs = pkg.HipScene(sd, device=local_rank)  # scene -> HBM, outside the timed region
+    fb = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    spp_step = args.spp_per_step
+    total_spp = spp_step * args.steps
+
+    def step(k, spp_total, accumulate):
+        return hs.render_device(fb.data_ptr(), stream.cuda_stream, spp=spp_step, spp_total=spp_total,
+                                sample_offset=k * spp_step, accumulate=accumulate, seed=1, tile_size=32,
+                                rank=rank, nranks=world, n_dir_sample=args.n_dir, spp_per_pass=spp_step,
+                                pool_paths=args.pool_paths)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        step(k, max(1, args.warmup * spp_step), 1 if k else 0)
+    if distributed and args.warmup:
+        dist.reduce(fb, dst=0)
+    fb.zero_()
+
+    barrier()
+    t0 = time.perf_counter()
+    agg = None
+    for k in range(args.steps):
+        st = step(k, total_spp, 1)
+        d = st.as_dict()
+        agg = d if agg is None else {key: agg[key] + d[key] for key in d}
+    if distributed:
+        dist.reduce(fb, dst=0)  # RCCL framebuffer merge over xGMI, inside the timed region
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        cnt = torch.tensor([agg["samples"], agg["vertices"], agg["ref_scene_rays"], agg["closest_rays"], agg["shadow_rays"]],
+                           dtype=torch.float64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        tot_samples, tot_vertices, tot_ref_rays, tot_closest, tot_shadow = [float(x) for x in cnt.tolist()]
+    else:
+        tot_samples, tot_vertices, tot_ref_rays = float(agg["samples"]), float(agg["vertices"]), float(agg["ref_scene_rays"])
+        tot_closest, tot_shadow = float(agg["closest_rays"]), float(agg["shadow_rays"])
+
+    if rank != 0:
+        if distributed:
+            dist.destroy_process_group()
+        return
+
+    value = tot_samples / dt / 1e6
+    # ---- roofline of the dominant kernel (this rank's HIP-event sums over the timed region)
+    kern = {"k_trace<shadow>": (agg["ms_trace_shadow"], agg["n_trace_shadow"], agg["shadow_rays"]),
+            "k_trace<closest>": (agg["ms_trace_closest"], agg["n_trace_closest"], agg["closest_rays"]),
+            "k_shade": (agg["ms_shade"], agg["n_shade"], agg["shaded"])}
+    dom = max(kern, key=lambda k: kern[k][0])
+    ms, n_launch, units = kern[dom]
+    per_unit = BYTES_PER_VERTEX if dom == "k_shade" else BYTES_PER_RAY
+    roofline = None
+    if ms > 0 and n_launch > 0:
+        avg_ms = ms / n_launch
+        bytes_per_launch = per_unit * units / n_launch
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = load_traffic()
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": (traffic or {}).get(dom),
+                    "avg_launch_ms": round(avg_ms, 4), "launches": int(n_launch), "units_per_launch": round(units / n_launch, 1),
+                    "algorithmic_bytes_per_unit": per_unit,
+                    "kernel_ms": {k: round(v[0], 2) for k, v in kern.items()}}
+    job_bytes_per_sample = (BYTES_PER_RAY * tot_ref_rays + BYTES_PER_VERTEX * tot_vertices) / tot_samples + BYTES_PER_SAMPLE
+    job_gbs = value * 1e6 * job_bytes_per_sample / 1e9
+
+    # ---- PSNR vs the CPU oracle, same Philox seed, on a reduced configuration of the same scene
+    psnr = None
+    if not args.no_psnr:
+        from oracle import oracle as orc
+        small = make_scene(pkg, argparse.Namespace(**{**vars(args), "width": 240, "height": 136}))
+        a, _ = orc.OracleScene(small).render(spp=8, seed=1, n_dir_sample=args.n_dir)
+        b, _ = pkg.HipScene(small, device=local_rank).render(spp=8, seed=1, n_dir_sample=args.n_dir)
+        psnr = pkg.pngio.psnr_u8(pkg.pngio.tonemap_u8(a), pkg.pngio.tonemap_u8(b))
+
+    # ---- CPU baseline: the oracle (a port of the reference path) on this box's host cores, bounded sample
+    cpu = None
+    if not args.no_cpu_baseline and not distributed:
+        from oracle import oracle as orc
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        osc = orc.OracleScene(sd)
+        _, cst = osc.render(spp=args.cpu_spp, seed=1, n_threads=ncores, n_dir_sample=args.n_dir)
+        cpu = {"value": round(cst.samples / cst.seconds / 1e6, 4), "unit": "Msamples/s", "cores": ncores, "kind": "port",
+               "sample": "%s %dx%d spp %d, n_dir %d, OpenMP schedule(dynamic,8), %.1f s" %
+                         (args.scene, W, H, args.cpu_spp, args.n_dir, cst.seconds)}
+
+    if args.save_png:
+        img = pkg.pngio.tonemap_u8(fb.cpu().numpy().reshape(H, W, 3))
+        pkg.pngio.write_png(args.save_png, img)
+
+    out = {
+        "metric": "Msamples/s (pixels x spp), chess scene 1920x1080, PSNR vs CPU",
+        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s %dx%d, %d spp per step, n_dir_sample %d, RR %.2f, DoF %s, constant sky colour"
+                               % (args.scene, W, H, spp_step, args.n_dir, sd.rr_rate, "on" if int(sd.camera["use_dof"]) else "off"),
+                   "partition": "interleaved 32x32 tiles over %d rank(s), RCCL reduce of the framebuffer" % world},
+        "wall_clock_1920x1080_spp2048_s": round(1920 * 1080 * 2048 / (value * 1e6), 2),
+        "psnr_vs_cpu_db": None if psnr is None else round(psnr, 2),
+        "psnr_config": "%s 240x136 spp 8, same Philox seed" % args.scene,
+        "roofline": roofline,
+        "job": {"bytes_per_sample": round(job_bytes_per_sample, 1), "achieved_GBps": round(job_gbs, 2),
+                "frac_of_hbm_peak": round(job_gbs / HBM_PEAK_GBS, 5),
+                "ref_rays_per_sample": round(tot_ref_rays / tot_samples, 3), "vertices_per_sample": round(tot_vertices / tot_samples, 3),
+                "traced_rays_per_sample": round((tot_closest + tot_shadow) / tot_samples, 3),
+                "Mrays_per_s_traced": round((tot_closest + tot_shadow) / dt / 1e6, 1),
+                "wavefront_iterations": int(agg["iterations"])},
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
