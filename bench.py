@@ -55,6 +55,20 @@ def make_scene(pkg, args):
     return pkg.scenes.cornell_rc(args.width, args.height, args.spp_per_step)
 
 
+def host_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU box
+    exposes every host core but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def load_traffic():
     """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc pass (profiles/), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -173,7 +187,7 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and not distributed:
         from oracle import oracle as orc
-        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncores = host_cores()
         osc = orc.OracleScene(sd)
         _, cst = osc.render(spp=args.cpu_spp, seed=1, n_threads=ncores, n_dir_sample=args.n_dir)
         cpu = {"value": round(cst.samples / cst.seconds / 1e6, 4), "unit": "Msamples/s", "cores": ncores, "kind": "port",

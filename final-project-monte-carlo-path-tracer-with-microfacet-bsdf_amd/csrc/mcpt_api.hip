@@ -236,7 +236,7 @@ void build_pixel_list(int W, int H, int tile, int rank, int nranks, std::vector<
 }
 
 struct LoopTotals {
-    uint64_t iterations = 0, shaded = 0, closest = 0, shadow = 0, fresh_paths = 0;
+    uint64_t iterations = 0, shaded = 0, closest = 0, shadow = 0;
 };
 
 // Runs the wavefront loop until `n_work` units (camera samples in mode 0, explicit paths in mode 1) are
@@ -249,12 +249,9 @@ int run_wavefront(mcpt_scene *sc, const RenderConst &C0, const CameraConst *cam,
     const uint32_t pool = w.pool;
     const int n_dir = C.n_dir;
     launch_init_free(w.free_slots.p, w.counters.p, pool, st);
-    uint32_t n_free = pool;
     uint32_t next_work = 0;
     int cur = 0;
-    uint32_t n_paths = 0;    // records in wave[cur]
-    uint32_t n_pending = 0;  // of which the first n_pending have a pending vertex (and shadow rays)
-    uint32_t n_rays = 0;
+    uint32_t n_cur_max = 0;  // upper bound of the record count of wave[cur] (the exact count lives on the device)
 
     // prologue: fill the pool
     {
@@ -262,70 +259,65 @@ int run_wavefront(mcpt_scene *sc, const RenderConst &C0, const CameraConst *cam,
         if (C.mode == 0) {
             const uint32_t g = std::min<uint32_t>(n_work, pool / 3);
             int ev = T.begin(st);
-            launch_generate(*cam, C, nx, 0, g, 0, 0, n_free, st);
+            launch_primary(sc->view, *cam, C, nx, cur, 0, g, st);
             T.end(ev, K_GENERATE, st);
-            n_free -= 3 * g;
             next_work = g;
-            n_paths = 3 * g;
-            n_rays = g;
-            tot.fresh_paths += 3ull * g;
+            n_cur_max = 3 * g;
+            tot.closest += g;
         } else {
             // explicit rays were uploaded into wave[cur].ray_o/ray_d by the caller
-            launch_generate_explicit(C, nx, n_work, st);
-            HIP_TRY(hipMemsetAsync(&w.counters.p->n_free, 0, sizeof(uint32_t), st));
-            n_free = 0;
+            launch_generate_explicit(C, nx, cur, n_work, st);
             next_work = n_work;
-            n_paths = n_work;
-            n_rays = n_work;
-            tot.fresh_paths += n_work;
+            n_cur_max = n_work;
+            int ev = T.begin(st);
+            launch_trace_closest(sc->view, n_work, nx.ray_o, nx.ray_d, nx.hit, st);
+            T.end(ev, K_CLOSEST, st);
+            tot.closest += n_work;
         }
-        int ev = T.begin(st);
-        launch_trace_closest(sc->view, n_rays, nx.ray_o, nx.ray_d, nx.hit, st);
-        T.end(ev, K_CLOSEST, st);
-        tot.closest += n_rays;
     }
 
-    while (n_paths > 0) {
-        Wave cw = w.wave[cur].view(), nx = w.wave[cur ^ 1].view();
-        HIP_TRY(hipMemsetAsync(w.counters.p, 0, 2 * sizeof(uint32_t), st));  // n_next, n_cont
+    while (n_cur_max > 0) {
+        const int nxt = cur ^ 1;
+        Wave cw = w.wave[cur].view(), nx = w.wave[nxt].view();
+        HIP_TRY(hipMemsetAsync(&w.counters.p->n_paths[nxt], 0, sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(&w.counters.p->n_rays[nxt], 0, sizeof(uint32_t), st));
         int ev = T.begin(st);
-        launch_shade(sc->view, C, cw, nx, n_paths, st);
+        launch_shade(sc->view, C, cw, nx, cur, n_cur_max, st);
         T.end(ev, K_SHADE, st);
         HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         T.collect();
-        const uint32_t n_next = w.h_counters->n_next, n_cont = w.h_counters->n_cont;
-        n_free = w.h_counters->n_free;
+        const uint32_t n_next = w.h_counters->n_paths[nxt].v, n_cont = w.h_counters->n_rays[nxt].v;
+        const uint32_t n_free = w.h_counters->n_free.v;
         tot.iterations++;
         tot.shaded += n_next;
 
+        if (n_cont > 0) {
+            ev = T.begin(st);
+            launch_trace_closest(sc->view, n_cont, nx.ray_o, nx.ray_d, nx.hit, st);
+            T.end(ev, K_CLOSEST, st);
+            tot.closest += n_cont;
+        }
+        if (C.enable_shadow && n_next > 0) {
+            ev = T.begin(st);
+            launch_trace_shadow(sc->view, n_next * (uint32_t)n_dir, n_dir, nx.sh_org, nx.sh_dir, nx.contrib, st);
+            T.end(ev, K_SHADOW, st);
+            tot.shadow += (uint64_t)n_next * n_dir;
+        }
         uint32_t g = 0;
         if (C.mode == 0 && next_work < n_work) {
             g = std::min<uint32_t>(n_work - next_work, std::min<uint32_t>((pool - n_next) / 3, n_free / 3));
             ev = T.begin(st);
-            launch_generate(*cam, C, nx, next_work, g, n_next, n_cont, n_free, st);
+            launch_primary(sc->view, *cam, C, nx, nxt, next_work, g, st);
             T.end(ev, K_GENERATE, st);
             next_work += g;
-            tot.fresh_paths += 3ull * g;
+            tot.closest += g;
         }
-        n_pending = n_next;
-        n_paths = n_next + 3 * g;
-        n_rays = n_cont + g;
-        ev = T.begin(st);
-        launch_trace_closest(sc->view, n_rays, nx.ray_o, nx.ray_d, nx.hit, st);
-        T.end(ev, K_CLOSEST, st);
-        tot.closest += n_rays;
-        if (C.enable_shadow && n_pending > 0) {
-            ev = T.begin(st);
-            launch_trace_shadow(sc->view, n_pending * (uint32_t)n_dir, n_dir, nx.sh_org, nx.sh_dir, nx.contrib, st);
-            T.end(ev, K_SHADOW, st);
-            tot.shadow += (uint64_t)n_pending * n_dir;
-        }
-        cur ^= 1;
+        n_cur_max = n_next + 3 * g;
+        cur = nxt;
     }
     HIP_TRY(hipStreamSynchronize(st));
     T.collect();
-    (void)n_pending;
     return MCPT_OK;
 }
 
@@ -395,8 +387,8 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
         C.sample_offset = p.sample_offset + k0;
         const int rc = run_wavefront(sc, C, &cc, n_pix * (uint32_t)s_now, st, tot);
         if (rc != MCPT_OK) return rc;
-        pushes += w.h_counters->pushes;
-        overflow += w.h_counters->overflow;
+        pushes += w.h_counters->pushes.v;
+        overflow += w.h_counters->overflow.v;
         int ev = sc->timer.begin(st);
         launch_accumulate(w.result.p, w.pixel_list.p, n_pix, s_now, spp_total, fb_dev, st);
         sc->timer.end(ev, K_RESOLVE, st);

@@ -11,15 +11,18 @@ constexpr uint32_t kFresh = 1u << 16;      // no pending vertex: the record's ra
 constexpr uint32_t kTerminate = 1u << 17;  // Russian roulette failed at the pending vertex (Scene.cpp:129,156)
 constexpr uint32_t kInside = 1u << 18;     // wo.n < 0 at the pending vertex (Scene.cpp:115)
 
-// Device counters, reset/read by the host once per wavefront iteration.
+// Device counters.  Every hot word sits on its own 128-byte line: the allocation atomics of different
+// queues then never serialise on one L2 line / memory channel.
+struct alignas(128) HotCounter {
+    uint32_t v;
+    uint32_t pad[31];
+};
 struct Counters {
-    uint32_t n_next;    // records appended to the next path list
-    uint32_t n_cont;    // continuation rays appended to the next closest-hit queue
-    uint32_t n_free;    // entries in the free-slot stack
-    uint32_t pushes;    // cumulative: recursion levels entered (castRay depth+1 calls)
-    uint32_t overflow;  // cumulative: paths cut by max_depth
-    uint32_t finished;  // cumulative: finished paths
-    uint32_t pad[2];
+    HotCounter n_paths[2];  // records in path list 0 / 1
+    HotCounter n_rays[2];   // entries in closest-hit queue 0 / 1
+    HotCounter n_free;      // entries in the free-slot stack
+    HotCounter pushes;      // cumulative: recursion levels entered (castRay depth+1 calls)
+    HotCounter overflow;    // cumulative: paths cut by max_depth
 };
 
 // One side of the double-buffered wavefront state (all SoA, 16-byte records, indexed by list position).
@@ -59,15 +62,19 @@ struct CameraConst {
 };
 
 void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, hipStream_t s);
-void launch_generate(const CameraConst &cam, const RenderConst &C, Wave next, uint32_t first_sample, uint32_t n_samples,
-                     uint32_t path_base, uint32_t ray_base, uint32_t n_free_before, hipStream_t s);
-void launch_generate_explicit(const RenderConst &C, Wave next, uint32_t n, hipStream_t s);
+// Camera ray + closest hit for `n_samples` new samples, fused: a miss or a depth-0 emitter hit writes the
+// three channel results directly; any other hit appends one ray/hit entry and three fresh path records to
+// wave `next` (list index `next_idx`).
+void launch_primary(const DevScene &S, const CameraConst &cam, const RenderConst &C, Wave next, int next_idx,
+                    uint32_t first_sample, uint32_t n_samples, hipStream_t s);
+void launch_generate_explicit(const RenderConst &C, Wave next, int next_idx, uint32_t n, hipStream_t s);
 void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const uint32_t *pixel, const uint32_t *sample,
                         float4 *o, float4 *d, hipStream_t s);
 void launch_trace_closest(const DevScene &S, uint32_t n, const float4 *ray_o, const float4 *ray_d, uint4 *hit, hipStream_t s);
 void launch_trace_shadow(const DevScene &S, uint32_t n_rays, int32_t n_dir, const float4 *sh_org, const float4 *sh_dir,
                          float *contrib, hipStream_t s);
-void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, uint32_t n_cur, hipStream_t s);
+// Shades list `cur_idx` (at most n_cur_max records; the true count is read from the device counter) into the other list.
+void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, int cur_idx, uint32_t n_cur_max, hipStream_t s);
 void launch_accumulate(const float *result, const uint32_t *pixel_list, uint32_t n_pix, int32_t s_pass, float spp_total,
                        float *fb, hipStream_t s);
 

@@ -5,8 +5,9 @@
 //                    hit), finishes the path or pushes a clamp-stack level, shades the next vertex and emits
 //                    n_dir shadow rays + at most one continuation ray; survivors are stream-compacted into
 //                    the next list with ballot/popcount wave-aggregated atomics.
-//   k_generate       camera rays for new samples (one primary ray feeds the three channel paths).
-//   k_trace<false>   closest hit for primary + continuation rays.
+//   k_primary        camera ray + closest hit for new samples, fused (one primary ray feeds the three channel
+//                    paths); sky misses and depth-0 emitter hits are finished here and never become records.
+//   k_trace<false>   closest hit for continuation rays.
 //   k_trace<true>    shadow rays: the distance-equality visibility of Scene.cpp:75.
 //   k_accumulate     per pass: framebuffer[m] += rgb/spp in sample order (Renderer.cpp:80).
 //
@@ -24,25 +25,51 @@ constexpr int kBlock = 256;
 
 MCPT_DI uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// Wave-aggregated slot allocation: one atomic per wavefront, prefix by mbcnt over the ballot mask.
-// Must be called by all lanes of the wave at a converged point.
-MCPT_DI uint32_t wave_alloc(bool want, uint32_t *counter) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return 0u;
-    const uint32_t total = (uint32_t)__popcll(mask);
-    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane_id() == leader) base = atomicAdd(counter, total);
-    base = (uint32_t)__shfl((int)base, leader);
-    return base + prefix;
-}
+// Block-aggregated queue allocation.  Up to kMaxAlloc counters are served by ONE round of atomics per
+// workgroup (lane k of wave 0 adds the block total of request k), instead of one returning atomic per
+// wave and counter: the hot counters are the only cross-workgroup contention points of the pipeline.
+// Must be called by every thread of the block (it contains barriers).
+constexpr int kMaxAlloc = 6;
+struct BlockAllocShared {
+    uint32_t cnt[kBlock / 64][kMaxAlloc];
+    uint32_t base[kMaxAlloc];
+};
 
-MCPT_DI void wave_count(bool want, uint32_t *counter) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return;
-    const int leader = __ffsll((long long)mask) - 1;
-    if ((int)lane_id() == leader) atomicAdd(counter, (uint32_t)__popcll(mask));
+template <int N>
+MCPT_DI void block_alloc(BlockAllocShared &sh, const bool (&want)[N], const uint32_t (&mult)[N], uint32_t *const (&counter)[N],
+                         const bool (&subtract)[N], uint32_t (&index)[N]) {
+    static_assert(N <= kMaxAlloc, "too many allocation requests");
+    const uint32_t lane = lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t prefix[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const unsigned long long mask = __ballot(want[k]);
+        prefix[k] = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (lane == 0) sh.cnt[wave][k] = (uint32_t)__popcll(mask);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (threadIdx.x == (unsigned)k) {  // lanes 0..N-1 of wave 0 issue their atomics in the same instruction
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) total += sh.cnt[w][k];
+            uint32_t base = 0;
+            if (total) {
+                const uint32_t amount = total * mult[k];
+                base = subtract[k] ? (atomicSub(counter[k], amount) - amount) : atomicAdd(counter[k], amount);
+            }
+            sh.base[k] = base;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; ++w) before += sh.cnt[w][k];
+        index[k] = sh.base[k] + (before + prefix[k]) * mult[k];
+    }
 }
 
 MCPT_DI f3 ld3(float4 v) { return mk3(v.x, v.y, v.z); }
@@ -57,29 +84,14 @@ MCPT_DI f3 ld3(float4 v) { return mk3(v.x, v.y, v.z); }
 // entry distance exceeds the best hit by a margin far above float rounding (closest hit) or lies beyond
 // the light sample (shadow rays).  Equal distances go to the larger primitive id.
 // ------------------------------------------------------------------------------------------------
+struct TraceResult {
+    double t;
+    int32_t prim;
+    bool visible;  // SHADOW only
+};
+
 template <bool SHADOW, int STK>
-__global__ __launch_bounds__(kBlock) void k_trace(DevScene S, uint32_t n, const float4 *__restrict__ ray_o,
-                                                  const float4 *__restrict__ ray_d, uint4 *__restrict__ hit,
-                                                  int32_t n_dir, const float4 *__restrict__ sh_org,
-                                                  const float4 *__restrict__ sh_dir, float *__restrict__ contrib) {
-    __shared__ int32_t stk[STK][kBlock];
-    const int tid = threadIdx.x;
-    const uint32_t i = blockIdx.x * kBlock + tid;
-    if (i >= n) return;
-
-    f3 o, d;
-    float dist = 0.f;
-    if (SHADOW) {
-        const float4 dd = sh_dir[i];
-        o = ld3(sh_org[i / (uint32_t)n_dir]);
-        d = ld3(dd);
-        dist = dd.w;
-    } else {
-        o = ld3(ray_o[i]);
-        d = ld3(ray_d[i]);
-    }
-    const Ray r = make_ray(o, d);
-
+MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid) {
     double best_t = DBL_MAX;
     int32_t best_prim = -1;
     bool occluded = false, found = false;
@@ -146,13 +158,41 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene S, uint32_t n, const 
             cur = stk[--sp][tid];
         }
     }
+    // Scene.cpp:74-75: a light sample counts iff the CLOSEST hit lies within EPSILON of the light distance.
+    return TraceResult{best_t, best_prim, !occluded && found};
+}
 
+MCPT_DI uint4 pack_hit(double t, int32_t prim) {
+    const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+    return make_uint4((uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)prim, 0u);
+}
+
+template <bool SHADOW, int STK>
+__global__ __launch_bounds__(kBlock) void k_trace(DevScene S, uint32_t n, const float4 *__restrict__ ray_o,
+                                                  const float4 *__restrict__ ray_d, uint4 *__restrict__ hit,
+                                                  int32_t n_dir, const float4 *__restrict__ sh_org,
+                                                  const float4 *__restrict__ sh_dir, float *__restrict__ contrib) {
+    __shared__ int32_t stk[STK][kBlock];
+    const int tid = threadIdx.x;
+    const uint32_t i = blockIdx.x * kBlock + tid;
+    if (i >= n) return;
+    f3 o, d;
+    float dist = 0.f;
     if (SHADOW) {
-        // Scene.cpp:74-75: the sample counts iff the CLOSEST hit lies within EPSILON of the light distance.
-        if (occluded || !found) contrib[i] = 0.f;
+        const float4 dd = sh_dir[i];
+        o = ld3(sh_org[i / (uint32_t)n_dir]);
+        d = ld3(dd);
+        dist = dd.w;
     } else {
-        const unsigned long long tb = (unsigned long long)__double_as_longlong(best_t);
-        hit[i] = make_uint4((uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)best_prim, 0u);
+        o = ld3(ray_o[i]);
+        d = ld3(ray_d[i]);
+    }
+    const Ray r = make_ray(o, d);
+    const TraceResult tr = traverse<SHADOW, STK>(S, r, dist, stk, tid);
+    if (SHADOW) {
+        if (!tr.visible) contrib[i] = 0.f;
+    } else {
+        hit[i] = pack_hit(tr.t, tr.prim);
     }
 }
 
@@ -205,30 +245,86 @@ MCPT_DI void camera_ray(const CameraConst &cam, uint32_t seed, uint32_t m, uint3
     dir = mat3_mul(cam.orient, dir);  // Renderer.cpp:76
 }
 
-__global__ __launch_bounds__(kBlock) void k_generate(CameraConst cam, RenderConst C, Wave next, uint32_t first_sample,
-                                                     uint32_t n_samples, uint32_t path_base, uint32_t ray_base,
-                                                     uint32_t n_free_before) {
-    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= n_samples) return;
+// k_primary: Renderer.cpp:44-79 up to the first Scene::intersect of castRay (Scene.cpp:87) for new samples.
+// The three channel paths of a sample share the primary ray, so it is generated and traced once.
+//   miss (Scene.cpp:88-95) ............ result[3 channels] = environment, no records
+//   depth-0 emitter (Scene.cpp:102-107)  result[3 channels] = clamp(0,1, emission * |wo.n|), no records
+//   surface ........................... one ray + hit entry, three fresh path records, three clamp-stack slots
+template <int STK>
+__global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam, RenderConst C, Wave next, int next_idx,
+                                                    uint32_t first_sample, uint32_t n_samples) {
+    __shared__ int32_t stk[STK][kBlock];
+    __shared__ BlockAllocShared sh;
+    const int tid = threadIdx.x;
+    const uint32_t j = blockIdx.x * kBlock + tid;
+    const bool valid = j < n_samples;
     const uint32_t s = first_sample + j;
-    const uint32_t pl = s / (uint32_t)C.s_pass;
-    const uint32_t m = C.pixel_list ? C.pixel_list[pl] : pl;
-    const uint32_t k = (uint32_t)C.sample_offset + (s % (uint32_t)C.s_pass);
-    f3 pos, dir;
-    camera_ray(cam, C.seed, m, k, pos, dir);
-    next.ray_o[ray_base + j] = make_float4(pos.x, pos.y, pos.z, 0.f);
-    next.ray_d[ray_base + j] = make_float4(dir.x, dir.y, dir.z, 0.f);
+    bool surface = false;
+    f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1);
+    TraceResult tr{DBL_MAX, -1, false};
+    if (valid) {
+        const uint32_t pl = s / (uint32_t)C.s_pass;
+        const uint32_t m = C.pixel_list ? C.pixel_list[pl] : pl;
+        const uint32_t k = (uint32_t)C.sample_offset + (s % (uint32_t)C.s_pass);
+        camera_ray(cam, C.seed, m, k, pos, dir);
+        const Ray r = make_ray(pos, dir);
+        tr = traverse<false, STK>(S, r, 0.f, stk, tid);
+        if (tr.prim < 0) {
+            const f3 env = sample_env(S, dir);
+            C.result[(size_t)s * 3 + 0] = env.x;
+            C.result[(size_t)s * 3 + 1] = env.y;
+            C.result[(size_t)s * 3 + 2] = env.z;
+        } else {
+            int mat;
+            f3 n;
+            if (tr.prim < S.n_tri) {
+                const TriShade ts = S.tri_shade[tr.prim];
+                mat = ts.mat;
+                n = mk3(ts.n[0], ts.n[1], ts.n[2]);
+            } else {
+                const SphereRec sp = S.spheres[tr.prim - S.n_tri];
+                mat = sp.mat;
+                const f3 p = pos + dir * (float)tr.t;
+                n = normalized(p - mk3(sp.c[0], sp.c[1], sp.c[2]));
+            }
+            const MaterialRec &M = S.mats[mat];
+            if (M.hasEmission) {
+                const float c = fabsf(dot(-dir, n));
+                C.result[(size_t)s * 3 + 0] = clampf(0, 1, M.emit[0] * c);
+                C.result[(size_t)s * 3 + 1] = clampf(0, 1, M.emit[1] * c);
+                C.result[(size_t)s * 3 + 2] = clampf(0, 1, M.emit[2] * c);
+            } else {
+                surface = true;
+            }
+        }
+    }
+    const bool want[3] = {surface, surface, surface};
+    const uint32_t mult[3] = {1u, 3u, 3u};
+    uint32_t *const ctr[3] = {&C.counters->n_rays[next_idx].v, &C.counters->n_paths[next_idx].v, &C.counters->n_free.v};
+    const bool sub[3] = {false, false, true};
+    uint32_t idx[3];
+    block_alloc<3>(sh, want, mult, ctr, sub, idx);
+    if (!surface) return;
+    const uint32_t ri = idx[0], pi = idx[1], fi = idx[2];
+    next.ray_o[ri] = make_float4(pos.x, pos.y, pos.z, 0.f);
+    next.ray_d[ri] = make_float4(dir.x, dir.y, dir.z, 0.f);
+    next.hit[ri] = pack_hit(tr.t, tr.prim);
 #pragma unroll
     for (uint32_t c = 0; c < 3; ++c) {
-        const uint32_t slot = C.free_slots[n_free_before - 1u - (3u * j + c)];
-        next.rec0[path_base + 3u * j + c] = make_uint4(s * 3u + c, ray_base + j, kFresh, 0u);
-        next.rec1[path_base + 3u * j + c] = make_float4(0.f, 0.f, 0.f, __uint_as_float(slot));
+        const uint32_t slot = C.free_slots[fi + c];
+        next.rec0[pi + c] = make_uint4(s * 3u + c, ri, kFresh, 0u);
+        next.rec1[pi + c] = make_float4(0.f, 0.f, 0.f, __uint_as_float(slot));
     }
-    if (j == 0) C.counters->n_free = n_free_before - 3u * n_samples;
 }
 
-__global__ __launch_bounds__(kBlock) void k_generate_explicit(Wave next, uint32_t n) {
+// mcpt_cast_rays: caller-supplied rays, one fresh record per ray; the rays are traced by k_trace<false>.
+__global__ __launch_bounds__(kBlock) void k_generate_explicit(Wave next, Counters *c, int next_idx, uint32_t n) {
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j == 0) {
+        c->n_paths[next_idx].v = n;
+        c->n_rays[next_idx].v = n;
+        c->n_free.v = 0;
+    }
     if (j >= n) return;
     next.rec0[j] = make_uint4(j, j, kFresh, 0u);
     next.rec1[j] = make_float4(0.f, 0.f, 0.f, __uint_as_float(j));
@@ -248,12 +344,11 @@ __global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Coun
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
     if (j < pool) free_slots[j] = j;
     if (j == 0) {
-        c->n_next = 0;
-        c->n_cont = 0;
-        c->n_free = pool;
-        c->pushes = 0;
-        c->overflow = 0;
-        c->finished = 0;
+        c->n_paths[0].v = c->n_paths[1].v = 0;
+        c->n_rays[0].v = c->n_rays[1].v = 0;
+        c->n_free.v = pool;
+        c->pushes.v = 0;
+        c->overflow.v = 0;
     }
 }
 
@@ -327,9 +422,12 @@ MCPT_DI float unwind(const RenderConst &C, uint32_t slot, uint32_t depth, float 
     return X;
 }
 
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wave cur, Wave next, uint32_t n_cur) {
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wave cur, Wave next, int cur_idx) {
+    __shared__ BlockAllocShared sh;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n_cur = C.counters->n_paths[cur_idx].v;  // the grid is an upper bound; the list length lives on the device
     const bool valid = i < n_cur;
+    const int next_idx = cur_idx ^ 1;
 
     uint32_t pid = 0, slot = 0, depth = 0, ray_idx = 0;
     int ch = 0;
@@ -432,17 +530,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wav
         }
     }
 
-    // ---- finish: unwind the clamp stack, publish the path value, release the slot
+    // ---- finish: unwind the clamp stack and publish the path value
     if (finished) {
         X = unwind(C, slot, depth, X);
         C.result[pid] = X;
-    }
-    {
-        const uint32_t fi = wave_alloc(finished, &C.counters->n_free);
-        if (finished) C.free_slots[fi] = slot;
-        wave_count(finished, &C.counters->finished);
-        wave_count(pushed, &C.counters->pushes);
-        wave_count(overflow, &C.counters->overflow);
     }
 
     // ---- shade the new vertex: Scene.cpp:109-128,150-155
@@ -450,8 +541,21 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wav
     float u0[4] = {0.f, 0.f, 1.f, 0.f};
     if (do_shade) rng_block(key, depth, 0u, u0);
     const bool has_cont = do_shade && !(u0[2] >= C.rr_rate);  // Scene.cpp:121,129,156
-    const uint32_t j = wave_alloc(do_shade, &C.counters->n_next);
-    const uint32_t rj = wave_alloc(has_cont, &C.counters->n_cont);
+
+    // one round of block-aggregated atomics: released slots, next-list records, continuation rays, statistics
+    uint32_t j, rj;
+    {
+        const bool want[5] = {finished, do_shade, has_cont, pushed, overflow};
+        const uint32_t mult[5] = {1u, 1u, 1u, 1u, 1u};
+        uint32_t *const ctr[5] = {&C.counters->n_free.v, &C.counters->n_paths[next_idx].v, &C.counters->n_rays[next_idx].v,
+                                  &C.counters->pushes.v, &C.counters->overflow.v};
+        const bool sub[5] = {false, false, false, false, false};
+        uint32_t idx[5];
+        block_alloc<5>(sh, want, mult, ctr, sub, idx);
+        if (finished) C.free_slots[idx[0]] = slot;
+        j = idx[1];
+        rj = idx[2];
+    }
     if (!do_shade) return;
 
     const f3 mfn = mat_sample(m, n, u0[0], u0[1]);   // Scene.cpp:109
@@ -525,17 +629,19 @@ void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, hipStrea
     hipLaunchKernelGGL(k_init_free, dim3(blocks(pool)), dim3(kBlock), 0, s, free_slots, c, pool);
 }
 
-void launch_generate(const CameraConst &cam, const RenderConst &C, Wave next, uint32_t first_sample, uint32_t n_samples,
-                     uint32_t path_base, uint32_t ray_base, uint32_t n_free_before, hipStream_t s) {
+void launch_primary(const DevScene &S, const CameraConst &cam, const RenderConst &C, Wave next, int next_idx,
+                    uint32_t first_sample, uint32_t n_samples, hipStream_t s) {
     if (n_samples == 0) return;
-    hipLaunchKernelGGL(k_generate, dim3(blocks(n_samples)), dim3(kBlock), 0, s, cam, C, next, first_sample, n_samples, path_base,
-                       ray_base, n_free_before);
+    const dim3 g(blocks(n_samples)), b(kBlock);
+    if (S.height <= 16) hipLaunchKernelGGL((k_primary<16>), g, b, 0, s, S, cam, C, next, next_idx, first_sample, n_samples);
+    else if (S.height <= 24) hipLaunchKernelGGL((k_primary<24>), g, b, 0, s, S, cam, C, next, next_idx, first_sample, n_samples);
+    else if (S.height <= 32) hipLaunchKernelGGL((k_primary<32>), g, b, 0, s, S, cam, C, next, next_idx, first_sample, n_samples);
+    else hipLaunchKernelGGL((k_primary<kMaxBvhHeight>), g, b, 0, s, S, cam, C, next, next_idx, first_sample, n_samples);
 }
 
-void launch_generate_explicit(const RenderConst &C, Wave next, uint32_t n, hipStream_t s) {
-    (void)C;
+void launch_generate_explicit(const RenderConst &C, Wave next, int next_idx, uint32_t n, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_generate_explicit, dim3(blocks(n)), dim3(kBlock), 0, s, next, n);
+    hipLaunchKernelGGL(k_generate_explicit, dim3(blocks(n)), dim3(kBlock), 0, s, next, C.counters, next_idx, n);
 }
 
 void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const uint32_t *pixel, const uint32_t *sample,
@@ -566,9 +672,9 @@ void launch_trace_shadow(const DevScene &S, uint32_t n_rays, int32_t n_dir, cons
     launch_trace<true>(S, n_rays, nullptr, nullptr, nullptr, n_dir, sh_org, sh_dir, contrib, s);
 }
 
-void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, uint32_t n_cur, hipStream_t s) {
-    if (n_cur == 0) return;
-    hipLaunchKernelGGL(k_shade, dim3(blocks(n_cur)), dim3(kBlock), 0, s, S, C, cur, next, n_cur);
+void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, int cur_idx, uint32_t n_cur_max, hipStream_t s) {
+    if (n_cur_max == 0) return;
+    hipLaunchKernelGGL(k_shade, dim3(blocks(n_cur_max)), dim3(kBlock), 0, s, S, C, cur, next, cur_idx);
 }
 
 void launch_accumulate(const float *result, const uint32_t *pixel_list, uint32_t n_pix, int32_t s_pass, float spp_total,
