@@ -159,6 +159,7 @@ struct mcpt_scene {
     DevBuf<LightNode> light_nodes;
     DevBuf<LightTri> light_tris;
     DevBuf<float> env;
+    DevBuf<unsigned long long> dbg;
     DevScene view{};
     Workspace ws;
     Timer timer;
@@ -341,7 +342,7 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     s_pass = std::min(s_pass, p.spp);
     while ((uint64_t)n_pix * s_pass * 3ull > 0xfffffff0ull && s_pass > 1) s_pass /= 2;
     const int max_depth = derive_max_depth(p);
-    uint64_t pool64 = p.pool_paths > 0 ? (uint64_t)p.pool_paths : (3ull << 20);
+    uint64_t pool64 = p.pool_paths > 0 ? (uint64_t)p.pool_paths : (12ull << 20);
     pool64 = std::max<uint64_t>(pool64, 3 * 256);
     // keep the clamp stack within 48 GiB
     while (pool64 * (uint64_t)max_depth * 16ull > (48ull << 30) && pool64 > 3 * 4096) pool64 /= 2;
@@ -492,6 +493,13 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
     v.env_w = hs.env_w;
     v.env_h = hs.env_h;
     v.height = hs.height;
+    v.dbg = nullptr;
+#ifdef MCPT_TRAVERSAL_STATS
+    if (sc->dbg.alloc(16) == hipSuccess) {
+        (void)hipMemset(sc->dbg.p, 0, 16 * sizeof(unsigned long long));
+        v.dbg = sc->dbg.p;
+    }
+#endif
     sc->info.n_nodes = (int32_t)hs.nodes.size();
     sc->info.bvh_height = hs.height;
     sc->info.n_lights = v.n_lights;
@@ -506,6 +514,21 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
 void mcpt_scene_destroy(mcpt_scene *sc) {
     if (!sc) return;
     (void)hipSetDevice(sc->device);
+#ifdef MCPT_TRAVERSAL_STATS
+    if (sc->dbg.p) {
+        unsigned long long h[16];
+        if (hipMemcpy(h, sc->dbg.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int k = 0; k < 2; ++k) {
+                const unsigned long long *d = h + 8 * k;
+                if (!d[0]) continue;
+                std::fprintf(stderr, "[mcpt traversal stats] %s: rays %llu, node visits/ray %.2f, prim tests/ray %.2f, %s %.3f, found %.3f, SIMD efficiency %.3f\n",
+                             k ? "shadow" : "closest", d[0], (double)d[1] / d[0], (double)d[2] / d[0], k ? "occluded" : "hit",
+                             (double)d[3] / d[0], (double)d[5] / d[0], (double)(d[1] + d[2]) / (double)d[4]);
+            }
+        }
+        sc->dbg.release();
+    }
+#endif
     sc->ws.release();
     sc->timer.release();
     sc->nodes.release(); sc->tri_geom.release(); sc->tri_shade.release(); sc->spheres.release(); sc->mats.release();

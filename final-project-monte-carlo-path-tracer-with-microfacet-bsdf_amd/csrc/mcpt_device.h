@@ -91,6 +91,7 @@ struct DevScene {
     float root_min[3], root_max[3];
     float background[3];
     int32_t root, n_tri, n_lights, env_w, env_h, height;
+    unsigned long long *dbg;  // traversal statistics (only written by -DMCPT_TRAVERSAL_STATS builds)
 };
 
 // ---------------------------------------------------------------- ray / box / primitive tests
@@ -98,17 +99,21 @@ struct Ray {
     f3 o, d, inv;
 };
 
-MCPT_DI Ray make_ray(f3 o, f3 d) {  // Ray.hpp:13-18: the inverse goes through a double division
+// Ray.hpp:13-18 computes the inverse as (float)(1. / (double)d).  For a single division of float operands,
+// rounding to double first and to float second is innocuous (double has 53 >= 2*24 + 2 significand bits), so
+// the result is bit-identical to the correctly rounded f32 division below (hipcc's default for `/`);
+// tests/test_gpu_parity.py::test_intersect_bit_exact keeps this honest.
+MCPT_DI Ray make_ray(f3 o, f3 d) {
     Ray r;
     r.o = o;
     r.d = d;
-    r.inv = mk3((float)(1. / (double)d.x), (float)(1. / (double)d.y), (float)(1. / (double)d.z));
+    r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     return r;
 }
 
 // Bounds3::IntersectP, Bounds3.hpp:95-108.  fmin/fmax ignore a NaN operand; the initializer-list
 // std::max/std::min keep a NaN that sits in the x slot.
-MCPT_DI bool box_hit(const float mn[3], const float mx[3], const Ray &r, float &tmin_out) {
+MCPT_DI bool box_hit(const float mn[3], const float mx[3], const Ray &r, float &tmin_out, float &tmax_out) {
     const float t1x = (mn[0] - r.o.x) * r.inv.x, t1y = (mn[1] - r.o.y) * r.inv.y, t1z = (mn[2] - r.o.z) * r.inv.z;
     const float t2x = (mx[0] - r.o.x) * r.inv.x, t2y = (mx[1] - r.o.y) * r.inv.y, t2z = (mx[2] - r.o.z) * r.inv.z;
     const float lx = fminf(t1x, t2x), ly = fminf(t1y, t2y), lz = fminf(t1z, t2z);
@@ -120,6 +125,7 @@ MCPT_DI bool box_hit(const float mn[3], const float mx[3], const Ray &r, float &
     if (hy < tmax) tmax = hy;
     if (hz < tmax) tmax = hz;
     tmin_out = tmin;
+    tmax_out = tmax;
     return (tmin - kEps <= tmax) && (tmax >= -kEps);
 }
 

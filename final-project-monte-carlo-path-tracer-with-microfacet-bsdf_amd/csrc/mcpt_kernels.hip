@@ -87,79 +87,135 @@ MCPT_DI f3 ld3(float4 v) { return mk3(v.x, v.y, v.z); }
 struct TraceResult {
     double t;
     int32_t prim;
-    bool visible;  // SHADOW only
+    bool visible;  // shadow queries only
 };
+
+// One traversal loop, three query kinds:
+//   kClosest   closest hit (BVH.cpp:95-116); subtrees entered beyond the best hit (+margin) are skipped.
+//   kWindow    shadow phase A: only subtrees whose [tmin,tmax] overlaps [dist-m, dist+m] are entered.  Finds
+//              every hit the visibility test |t - dist| < EPSILON (Scene.cpp:75) could accept; a hit with
+//              t <= dist - EPSILON met on the way proves occlusion at once.
+//   kOccluder  shadow phase B: any hit with t <= dist - EPSILON ends the search (subtrees entered beyond dist skipped).
+// The margin m = 1e-4*dist + 1e-2 is far above the float rounding of the slab test.
+enum { kClosest = 0, kWindow = 1, kOccluder = 2 };
+
+struct TraceState {
+    double best_t;
+    int32_t best_prim;
+    bool occluded, found;
+#ifdef MCPT_TRAVERSAL_STATS
+    unsigned nv, nt, iters;
+#endif
+};
+
+template <int MODE, int STK>
+MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, TraceState &st) {
+    const float margin = dist * 1e-4f + 1e-2f;
+    float lim = (MODE == kClosest) ? INFINITY : (dist + margin);
+    const float lo = dist - margin;
+    float tm, tx;
+    if (!box_hit(S.root_min, S.root_max, r, tm, tx)) return;
+    int32_t cur = S.root;
+    int sp = 0;
+    while (true) {
+#ifdef MCPT_TRAVERSAL_STATS
+        st.iters++;
+        if (cur >= 0) st.nv++;
+        else st.nt++;
+#endif
+        if (cur >= 0) {
+            const float4 *np = reinterpret_cast<const float4 *>(S.nodes + cur);
+            const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+            const float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
+            const float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
+            const int32_t left = __float_as_int(e.x), right = __float_as_int(e.y);
+            float tl = 0.f, tr = 0.f, txl = 0.f, txr = 0.f;
+            bool hl = (left != kNoChild) && box_hit(lmin, lmax, r, tl, txl);
+            bool hr = (right != kNoChild) && box_hit(rmin, rmax, r, tr, txr);
+            hl = hl && !(tl > lim);
+            hr = hr && !(tr > lim);
+            if (MODE == kWindow) {
+                hl = hl && !(txl < lo);
+                hr = hr && !(txr < lo);
+            }
+            if (hl && hr) {
+                const bool swap = tr < tl;
+                const int32_t nearc = swap ? right : left, farc = swap ? left : right;
+                if (sp < STK) stk[sp++][tid] = farc;
+                cur = nearc;
+                continue;
+            }
+            if (hl) {
+                cur = left;
+                continue;
+            }
+            if (hr) {
+                cur = right;
+                continue;
+            }
+        } else {
+            const int32_t prim = ~cur;
+            double t = 0, u, v;
+            bool h;
+            if (prim < S.n_tri) {
+                h = tri_hit(S.tri_geom[prim], r, t, u, v);
+            } else {
+                float ts = 0.f;
+                h = sphere_hit(S.spheres[prim - S.n_tri], r, ts);
+                t = (double)ts;
+            }
+            if (h) {
+                if (MODE != kClosest) {
+                    const double dd = t - (double)dist;
+                    if (dd <= -(double)kEps) {
+                        st.occluded = true;
+                        return;
+                    }
+                    if (fabs(dd) < (double)kEps) st.found = true;
+                } else if (t < st.best_t || (t == st.best_t && prim > st.best_prim)) {
+                    st.best_t = t;
+                    st.best_prim = prim;
+                    lim = (float)(t + (fabs(t) * 1e-4 + 1e-2));
+                }
+            }
+        }
+        if (sp == 0) return;
+        cur = stk[--sp][tid];
+    }
+}
 
 template <bool SHADOW, int STK>
 MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid) {
-    double best_t = DBL_MAX;
-    int32_t best_prim = -1;
-    bool occluded = false, found = false;
-    float lim = SHADOW ? (dist + (dist * 1e-4f + 1e-2f)) : INFINITY;
-
-    float tm;
-    if (box_hit(S.root_min, S.root_max, r, tm)) {
-        int32_t cur = S.root;
-        int sp = 0;
-        while (true) {
-            if (cur >= 0) {
-                const float4 *np = reinterpret_cast<const float4 *>(S.nodes + cur);
-                const float4 a = np[0], b = np[1], c = np[2], e = np[3];
-                const float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
-                const float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
-                const int32_t left = __float_as_int(e.x), right = __float_as_int(e.y);
-                float tl = 0.f, tr = 0.f;
-                bool hl = (left != kNoChild) && box_hit(lmin, lmax, r, tl);
-                bool hr = (right != kNoChild) && box_hit(rmin, rmax, r, tr);
-                hl = hl && !(tl > lim);
-                hr = hr && !(tr > lim);
-                if (hl && hr) {
-                    const bool swap = tr < tl;
-                    const int32_t nearc = swap ? right : left, farc = swap ? left : right;
-                    if (sp < STK) stk[sp++][tid] = farc;
-                    cur = nearc;
-                    continue;
-                }
-                if (hl) {
-                    cur = left;
-                    continue;
-                }
-                if (hr) {
-                    cur = right;
-                    continue;
-                }
-            } else {
-                const int32_t prim = ~cur;
-                double t = 0, u, v;
-                bool h;
-                if (prim < S.n_tri) {
-                    h = tri_hit(S.tri_geom[prim], r, t, u, v);
-                } else {
-                    float ts = 0.f;
-                    h = sphere_hit(S.spheres[prim - S.n_tri], r, ts);
-                    t = (double)ts;
-                }
-                if (h) {
-                    if (SHADOW) {
-                        const double dd = t - (double)dist;
-                        if (dd <= -(double)kEps) {
-                            occluded = true;
-                            break;
-                        }
-                        if (fabs(dd) < (double)kEps) found = true;
-                    } else if (t < best_t || (t == best_t && prim > best_prim)) {
-                        best_t = t;
-                        best_prim = prim;
-                        lim = (float)(t + (fabs(t) * 1e-4 + 1e-2));
-                    }
-                }
-            }
-            if (sp == 0) break;
-            cur = stk[--sp][tid];
-        }
+    TraceState st;
+    st.best_t = DBL_MAX;
+    st.best_prim = -1;
+    st.occluded = false;
+    st.found = false;
+#ifdef MCPT_TRAVERSAL_STATS
+    st.nv = st.nt = st.iters = 0;
+#endif
+    if (SHADOW) {
+        // Scene.cpp:74-75: a light sample counts iff the CLOSEST hit lies within EPSILON of the light distance,
+        // i.e. iff some hit lies in the window AND no hit lies at or below dist - EPSILON.
+        traverse_loop<kWindow, STK>(S, r, dist, stk, tid, st);
+        if (st.found && !st.occluded) traverse_loop<kOccluder, STK>(S, r, dist, stk, tid, st);
+    } else {
+        traverse_loop<kClosest, STK>(S, r, dist, stk, tid, st);
     }
-    // Scene.cpp:74-75: a light sample counts iff the CLOSEST hit lies within EPSILON of the light distance.
-    return TraceResult{best_t, best_prim, !occluded && found};
+#ifdef MCPT_TRAVERSAL_STATS
+    if (S.dbg) {  // [kind*8 + {rays, node visits, prim tests, occluded/hit, wave-iterations*64, found}]
+        const int base = SHADOW ? 8 : 0;
+        atomicAdd(&S.dbg[base + 0], 1ull);
+        atomicAdd(&S.dbg[base + 1], (unsigned long long)st.nv);
+        atomicAdd(&S.dbg[base + 2], (unsigned long long)st.nt);
+        atomicAdd(&S.dbg[base + 3], (unsigned long long)(SHADOW ? (st.occluded ? 1 : 0) : (st.best_prim >= 0 ? 1 : 0)));
+        unsigned mx = st.iters;
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+        if (lane_id() == 0) atomicAdd(&S.dbg[base + 4], (unsigned long long)mx * 64ull);
+        atomicAdd(&S.dbg[base + 5], (unsigned long long)(SHADOW ? (st.found ? 1 : 0) : 0));
+    }
+#endif
+    return TraceResult{st.best_t, st.best_prim, !st.occluded && st.found};
 }
 
 MCPT_DI uint4 pack_hit(double t, int32_t prim) {
@@ -179,6 +235,10 @@ __global__ __launch_bounds__(kBlock) void k_trace(DevScene S, uint32_t n, const 
     f3 o, d;
     float dist = 0.f;
     if (SHADOW) {
+        // A light sample whose contribution is exactly +-0 (Dirac BSDFs away from the mirror direction, back-facing
+        // configurations: Material.hpp:338,356,382,397) adds nothing to l_dir whether it is visible or not
+        // (Scene.cpp:76-79), so its shadow ray is not traced.  A NaN contribution is not zero and is traced.
+        if (contrib[i] == 0.f) return;
         const float4 dd = sh_dir[i];
         o = ld3(sh_org[i / (uint32_t)n_dir]);
         d = ld3(dd);

@@ -11,6 +11,7 @@
 // test it); std::stable_sort replaces the reference's unstable std::sort, whose tie order is unspecified.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -97,6 +98,91 @@ BNode *recursive_build(Arena &A, std::vector<BObj *> objs) {  // BVH.cpp:27-93
     const size_t mid = objs.size() / 2;
     node->left = recursive_build(A, std::vector<BObj *>(objs.begin(), objs.begin() + mid));
     node->right = recursive_build(A, std::vector<BObj *>(objs.begin() + mid, objs.end()));
+    node->bounds = box_union(node->left->bounds, node->right->bounds);
+    node->area = node->left->area + node->right->area;
+    return node;
+}
+
+// Alternative traversal tree: one binned-SAH BVH over ALL primitives (triangles and spheres), one primitive
+// per leaf.  Closest-hit results do not depend on the tree (ties go to the larger primitive id), except for
+// rays that graze a box face within float rounding, where the reference's own box test is decided by
+// rounding as well.  The default; MCPT_BVH=reference selects the reference topology.  Light sampling always keeps the reference trees.
+inline float half_area(const Box &b) {
+    const V3 d = b.mx - b.mn;
+    return d.x * d.y + d.y * d.z + d.z * d.x;
+}
+
+BNode *sah_build(Arena &A, std::vector<BObj *> &objs, size_t begin, size_t end) {
+    BNode *node = A.make();
+    const size_t n = end - begin;
+    if (n == 1) {
+        node->bounds = objs[begin]->bounds;
+        node->obj = objs[begin];
+        node->area = objs[begin]->area;
+        return node;
+    }
+    Box cb = box_empty();
+    for (size_t i = begin; i < end; ++i) cb = box_union(cb, centroid(objs[i]->bounds));
+    constexpr int kBins = 32;
+    float best_cost = std::numeric_limits<float>::infinity();
+    int best_axis = -1, best_split = -1;
+    for (int ax = 0; ax < 3; ++ax) {
+        const float lo = axis(cb.mn, ax), hi = axis(cb.mx, ax);
+        if (!(hi > lo)) continue;
+        Box bb[kBins];
+        int cnt[kBins];
+        for (int b = 0; b < kBins; ++b) {
+            bb[b] = box_empty();
+            cnt[b] = 0;
+        }
+        const float scale = kBins / (hi - lo);
+        for (size_t i = begin; i < end; ++i) {
+            int b = (int)((axis(centroid(objs[i]->bounds), ax) - lo) * scale);
+            b = std::min(std::max(b, 0), kBins - 1);
+            bb[b] = box_union(bb[b], objs[i]->bounds);
+            cnt[b]++;
+        }
+        float right_area[kBins];
+        int right_cnt[kBins];
+        Box acc = box_empty();
+        int c = 0;
+        for (int b = kBins - 1; b > 0; --b) {
+            acc = box_union(acc, bb[b]);
+            c += cnt[b];
+            right_area[b] = c ? half_area(acc) : 0.f;
+            right_cnt[b] = c;
+        }
+        acc = box_empty();
+        c = 0;
+        for (int b = 0; b < kBins - 1; ++b) {
+            acc = box_union(acc, bb[b]);
+            c += cnt[b];
+            if (c == 0 || right_cnt[b + 1] == 0) continue;
+            const float cost = half_area(acc) * c + right_area[b + 1] * right_cnt[b + 1];
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_axis = ax;
+                best_split = b;
+            }
+        }
+    }
+    size_t mid;
+    if (best_axis < 0) {
+        mid = begin + n / 2;  // all centroids coincide
+    } else {
+        const float lo = axis(cb.mn, best_axis), hi = axis(cb.mx, best_axis);
+        const float scale = kBins / (hi - lo);
+        const int ax = best_axis, split = best_split;
+        auto it = std::stable_partition(objs.begin() + begin, objs.begin() + end, [=](const BObj *o) {
+            int b = (int)((axis(centroid(o->bounds), ax) - lo) * scale);
+            b = std::min(std::max(b, 0), kBins - 1);
+            return b <= split;
+        });
+        mid = (size_t)(it - objs.begin());
+        if (mid == begin || mid == end) mid = begin + n / 2;
+    }
+    node->left = sah_build(A, objs, begin, mid);
+    node->right = sah_build(A, objs, mid, end);
     node->bounds = box_union(node->left->bounds, node->right->bounds);
     node->area = node->left->area + node->right->area;
     return node;
@@ -301,6 +387,19 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) 
     std::vector<BObj *> tops;
     for (BObj &b : top_objs) tops.push_back(&b);
     const BNode *root = recursive_build(arena, tops);  // Scene::buildBVH, Scene.cpp:14-17
+
+    // Default: the SAH tree.  MCPT_BVH=reference keeps the reference's two-level median-split topology.
+    const char *bvh_env = std::getenv("MCPT_BVH");
+    if (!(bvh_env && std::strcmp(bvh_env, "reference") == 0)) {
+        std::vector<BObj *> prims;
+        prims.reserve((size_t)d.n_triangles + d.n_objects);
+        for (int oi = 0; oi < d.n_objects; ++oi) {
+            if (top_objs[oi].prim >= 0) prims.push_back(&top_objs[oi]);  // sphere
+            else
+                for (int k = 0; k < d.objects[oi].n_tri; ++k) prims.push_back(&tri_objs[d.objects[oi].first_tri + k]);
+        }
+        root = sah_build(arena, prims, 0, prims.size());
+    }
 
     Flattener F{hs};
     hs.nodes.reserve((size_t)d.n_triangles + d.n_objects + 8);

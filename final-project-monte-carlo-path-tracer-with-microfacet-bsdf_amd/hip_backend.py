@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmcpt_hip.so")
+LIB_PATH = os.environ.get("MCPT_LIB") or os.path.join(HERE, "libmcpt_hip.so")  # MCPT_LIB: diagnostic builds only
 
 EXPORTS = ["mcpt_scene_create", "mcpt_scene_destroy", "mcpt_render", "mcpt_render_device", "mcpt_intersect",
            "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_last_error", "mcpt_version"]
