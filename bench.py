@@ -207,7 +207,7 @@ def main():
         "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %dx%d, %d spp per step, n_dir_sample %d, RR %.2f, DoF %s, constant sky colour"
-                               % (args.scene, W, H, spp_step, args.n_dir, sd.rr_rate, "on" if int(sd.camera["use_dof"]) else "off"),
+                               % (args.scene, W, H, spp_step, args.n_dir, sd.rr_rate, "on" if int(sd.camera["use_dof"].reshape(-1)[0]) else "off"),
                    "partition": "interleaved 32x32 tiles over %d rank(s), RCCL reduce of the framebuffer" % world},
         "wall_clock_1920x1080_spp2048_s": round(1920 * 1080 * 2048 / (value * 1e6), 2),
         "psnr_vs_cpu_db": None if psnr is None else round(psnr, 2),

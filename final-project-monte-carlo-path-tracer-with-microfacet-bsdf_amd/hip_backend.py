@@ -146,7 +146,7 @@ class HipScene:
     def render(self, camera=None, fb=None, **kw):
         """Renderer::Render up to the float framebuffer: returns (fb[H,W,3] float32, Stats)."""
         cam = np.ascontiguousarray(camera if camera is not None else self.sd.camera)
-        W, H = int(cam["width"]), int(cam["height"])
+        W, H = int(cam["width"].reshape(-1)[0]), int(cam["height"].reshape(-1)[0])
         if fb is None:
             fb = np.zeros((H, W, 3), dtype=np.float32)
         p = self.params(**kw)

@@ -25,7 +25,7 @@ import numpy as np
 
 f32 = np.float32
 
-# ---- POD layouts shared with include/mcpt.h (and, layout-identical, oracle/mcpt_oracle.h)
+# ---- POD layouts of include/mcpt.h
 TRI_DTYPE = np.dtype([("v0", f32, 3), ("v1", f32, 3), ("v2", f32, 3), ("t0", f32, 2), ("t1", f32, 2), ("t2", f32, 2)])
 MAT_DTYPE = np.dtype([("type", np.int32), ("textured", np.int32), ("roughness", f32), ("iorA", f32), ("iorB", f32),
                       ("base_reflectance", f32, 3), ("emission", f32, 3)])
