@@ -159,10 +159,11 @@ def main():
     kern = {"k_trace<shadow>": (agg["ms_trace_shadow"], agg["n_trace_shadow"], agg["shadow_rays"]),
             "k_trace<closest>": (agg["ms_trace_closest"], agg["n_trace_closest"], agg["closest_rays"] - agg["samples"]),
             "k_primary": (agg["ms_generate"], agg["n_generate"], agg["samples"]),
+            "k_direct": (agg["ms_direct"], agg["n_direct"], agg["shaded"]),
             "k_shade": (agg["ms_shade"], agg["n_shade"], agg["shaded"])}
     dom = max(kern, key=lambda k: kern[k][0])
     ms, n_launch, units = kern[dom]
-    per_unit = BYTES_PER_VERTEX if dom == "k_shade" else BYTES_PER_RAY
+    per_unit = BYTES_PER_VERTEX if dom in ("k_shade", "k_direct") else BYTES_PER_RAY
     roofline = None
     if ms > 0 and n_launch > 0:
         avg_ms = ms / n_launch

@@ -66,12 +66,11 @@ hipError_t upload(DevBuf<T> &b, const std::vector<T> &v) {
 
 struct WaveBufs {
     DevBuf<uint4> rec0, hit;
-    DevBuf<float4> rec1, ray_o, ray_d, sh_org, sh_dir;
+    DevBuf<float4> rec1, ray_o, ray_d;
     DevBuf<float> contrib;
-    Wave view() const { return Wave{rec0.p, rec1.p, ray_o.p, ray_d.p, hit.p, sh_org.p, sh_dir.p, contrib.p}; }
+    Wave view() const { return Wave{rec0.p, rec1.p, ray_o.p, ray_d.p, hit.p, contrib.p}; }
     void release() {
-        rec0.release(); hit.release(); rec1.release(); ray_o.release(); ray_d.release();
-        sh_org.release(); sh_dir.release(); contrib.release();
+        rec0.release(); hit.release(); rec1.release(); ray_o.release(); ray_d.release(); contrib.release();
     }
 };
 
@@ -79,6 +78,8 @@ struct Workspace {
     uint32_t pool = 0;
     int32_t n_dir = 0, max_depth = 0;
     WaveBufs wave[2];
+    DevBuf<float4> vtx0, vtx1, vtx2, shq_o, shq_d;
+    Scratch scratch() const { return Scratch{vtx0.p, vtx1.p, vtx2.p, shq_o.p, shq_d.p}; }
     DevBuf<float4> stack;
     DevBuf<float> result;
     DevBuf<uint32_t> free_slots, pixel_list, key_pixel, key_sample;
@@ -87,6 +88,7 @@ struct Workspace {
     Counters *h_counters = nullptr;  // pinned
     void release() {
         wave[0].release(); wave[1].release(); stack.release(); result.release(); free_slots.release();
+        vtx0.release(); vtx1.release(); vtx2.release(); shq_o.release(); shq_d.release();
         pixel_list.release(); key_pixel.release(); key_sample.release(); key_channel.release(); counters.release();
         if (h_counters) (void)hipHostFree(h_counters);
         h_counters = nullptr;
@@ -94,7 +96,7 @@ struct Workspace {
     }
 };
 
-enum KClass { K_CLOSEST = 0, K_SHADOW, K_SHADE, K_GENERATE, K_RESOLVE, K_NCLASS };
+enum KClass { K_CLOSEST = 0, K_SHADOW, K_SHADE, K_GENERATE, K_RESOLVE, K_DIRECT, K_NCLASS };
 
 struct Timer {
     bool enabled = true;
@@ -102,8 +104,8 @@ struct Timer {
     struct Rec { int a, b, cls; };
     std::vector<Rec> recs;
     size_t used = 0;
-    double ms[K_NCLASS] = {0, 0, 0, 0, 0};
-    uint64_t count[K_NCLASS] = {0, 0, 0, 0, 0};
+    double ms[K_NCLASS] = {0, 0, 0, 0, 0, 0};
+    uint64_t count[K_NCLASS] = {0, 0, 0, 0, 0, 0};
     int get() {
         if (used == pool.size()) {
             hipEvent_t e;
@@ -178,10 +180,13 @@ hipError_t ensure_workspace(mcpt_scene *sc, uint32_t pool, int32_t n_dir, int32_
         if ((e = b.ray_o.alloc(n_rays)) != hipSuccess) return e;
         if ((e = b.ray_d.alloc(n_rays)) != hipSuccess) return e;
         if ((e = b.hit.alloc(n_rays)) != hipSuccess) return e;
-        if ((e = b.sh_org.alloc(pool)) != hipSuccess) return e;
-        if ((e = b.sh_dir.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
         if ((e = b.contrib.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
     }
+    if ((e = w.vtx0.alloc(pool)) != hipSuccess) return e;
+    if ((e = w.vtx1.alloc(pool)) != hipSuccess) return e;
+    if ((e = w.vtx2.alloc(pool)) != hipSuccess) return e;
+    if ((e = w.shq_o.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
+    if ((e = w.shq_d.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
     if ((e = w.stack.alloc((size_t)pool * max_depth)) != hipSuccess) return e;
     if ((e = w.result.alloc(n_result)) != hipSuccess) return e;
     if ((e = w.free_slots.alloc(pool)) != hipSuccess) return e;
@@ -283,7 +288,7 @@ int run_wavefront(mcpt_scene *sc, const RenderConst &C0, const CameraConst *cam,
         HIP_TRY(hipMemsetAsync(&w.counters.p->n_paths[nxt], 0, sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(&w.counters.p->n_rays[nxt], 0, sizeof(uint32_t), st));
         int ev = T.begin(st);
-        launch_shade(sc->view, C, cw, nx, cur, n_cur_max, st);
+        launch_shade(sc->view, C, cw, nx, w.scratch(), cur, n_cur_max, st);
         T.end(ev, K_SHADE, st);
         HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -292,6 +297,7 @@ int run_wavefront(mcpt_scene *sc, const RenderConst &C0, const CameraConst *cam,
         const uint32_t n_free = w.h_counters->n_free.v;
         tot.iterations++;
         tot.shaded += n_next;
+        tot.shadow += w.h_counters->n_shadow.v;  // shadow queue length of the previous iteration
 
         if (n_cont > 0) {
             ev = T.begin(st);
@@ -299,11 +305,16 @@ int run_wavefront(mcpt_scene *sc, const RenderConst &C0, const CameraConst *cam,
             T.end(ev, K_CLOSEST, st);
             tot.closest += n_cont;
         }
-        if (C.enable_shadow && n_next > 0) {
+        HIP_TRY(hipMemsetAsync(&w.counters.p->n_shadow, 0, sizeof(uint32_t), st));
+        if (n_next > 0) {
             ev = T.begin(st);
-            launch_trace_shadow(sc->view, n_next * (uint32_t)n_dir, n_dir, nx.sh_org, nx.sh_dir, nx.contrib, st);
-            T.end(ev, K_SHADOW, st);
-            tot.shadow += (uint64_t)n_next * n_dir;
+            launch_direct(sc->view, C, nx, w.scratch(), n_next, st);
+            T.end(ev, K_DIRECT, st);
+            if (C.enable_shadow) {
+                ev = T.begin(st);
+                launch_trace_shadow(sc->view, w.counters.p, n_next * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
+                T.end(ev, K_SHADOW, st);
+            }
         }
         uint32_t g = 0;
         if (C.mode == 0 && next_work < n_work) {
@@ -417,6 +428,8 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
         stats->ms_shade = T.ms[K_SHADE];
         stats->ms_generate = T.ms[K_GENERATE];
         stats->ms_resolve = T.ms[K_RESOLVE];
+        stats->ms_direct = T.ms[K_DIRECT];
+        stats->n_direct = T.count[K_DIRECT];
         stats->n_trace_closest = T.count[K_CLOSEST];
         stats->n_trace_shadow = T.count[K_SHADOW];
         stats->n_shade = T.count[K_SHADE];

@@ -20,6 +20,7 @@ struct alignas(128) HotCounter {
 struct Counters {
     HotCounter n_paths[2];  // records in path list 0 / 1
     HotCounter n_rays[2];   // entries in closest-hit queue 0 / 1
+    HotCounter n_shadow;    // entries in the shadow-ray queue of the current iteration
     HotCounter n_free;      // entries in the free-slot stack
     HotCounter pushes;      // cumulative: recursion levels entered (castRay depth+1 calls)
     HotCounter overflow;    // cumulative: paths cut by max_depth
@@ -32,9 +33,17 @@ struct Wave {
     float4 *ray_o;    // closest-hit queue: origin
     float4 *ray_d;    // closest-hit queue: direction
     uint4 *hit;       // closest-hit results: {t lo, t hi, prim, 0}
-    float4 *sh_org;   // shadow rays: origin, one per path record
-    float4 *sh_dir;   // shadow rays: {direction, distance to the light sample}, n_dir per path record
-    float *contrib;   // per shadow ray: light-sample contribution; zeroed by the shadow kernel when occluded
+    float *contrib;   // n_dir per path record: light-sample contributions; zeroed by the shadow kernel when invisible
+};
+
+// Per-iteration scratch between k_shade, k_direct and k_trace<shadow> (single-buffered: produced and consumed
+// inside one iteration).
+struct Scratch {
+    float4 *vtx0;   // per record of the next list: {q.xyz (offset shading point, Scene.cpp:114), uv.x}
+    float4 *vtx1;   // {n.xyz, uv.y}
+    float4 *vtx2;   // {wo.xyz, bits: material | channel << 16 | inside << 18}
+    float4 *shq_o;  // compacted shadow queue: {origin.xyz, bits: index into contrib}
+    float4 *shq_d;  // {direction.xyz, distance to the light sample}
 };
 
 struct RenderConst {
@@ -71,10 +80,14 @@ void launch_generate_explicit(const RenderConst &C, Wave next, int next_idx, uin
 void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const uint32_t *pixel, const uint32_t *sample,
                         float4 *o, float4 *d, hipStream_t s);
 void launch_trace_closest(const DevScene &S, uint32_t n, const float4 *ray_o, const float4 *ray_d, uint4 *hit, hipStream_t s);
-void launch_trace_shadow(const DevScene &S, uint32_t n_rays, int32_t n_dir, const float4 *sh_org, const float4 *sh_dir,
-                         float *contrib, hipStream_t s);
+// Direct lighting (Scene::directLighting, Scene.cpp:56-82) for the n_records vertices shaded into `next`:
+// one lane per (vertex, light sample); fills next.contrib and appends the non-zero samples to the shadow queue.
+void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, uint32_t n_records, hipStream_t s);
+// Shadow queue (length in counters->n_shadow, at most n_max): zeroes contrib[] of invisible samples.
+void launch_trace_shadow(const DevScene &S, const Counters *counters, uint32_t n_max, Scratch X, float *contrib, hipStream_t s);
 // Shades list `cur_idx` (at most n_cur_max records; the true count is read from the device counter) into the other list.
-void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, int cur_idx, uint32_t n_cur_max, hipStream_t s);
+void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, Scratch X, int cur_idx, uint32_t n_cur_max,
+                  hipStream_t s);
 void launch_accumulate(const float *result, const uint32_t *pixel_list, uint32_t n_pix, int32_t s_pass, float spp_total,
                        float *fb, hipStream_t s);
 

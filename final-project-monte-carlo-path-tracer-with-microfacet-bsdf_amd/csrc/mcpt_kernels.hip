@@ -2,18 +2,21 @@
 //
 // Pipeline per wavefront iteration (host loop in mcpt_api.cpp):
 //   k_shade          one lane per path record: resolves the pending vertex (direct-light sum, continuation
-//                    hit), finishes the path or pushes a clamp-stack level, shades the next vertex and emits
-//                    n_dir shadow rays + at most one continuation ray; survivors are stream-compacted into
+//                    hit), finishes the path or pushes a clamp-stack level, samples the BSDF at the next vertex and
+//                    emits a vertex record + at most one continuation ray; survivors are stream-compacted into
 //                    the next list with ballot/popcount wave-aggregated atomics.
 //   k_primary        camera ray + closest hit for new samples, fused (one primary ray feeds the three channel
 //                    paths); sky misses and depth-0 emitter hits are finished here and never become records.
-//   k_trace<false>   closest hit for continuation rays.
-//   k_trace<true>    shadow rays: the distance-equality visibility of Scene.cpp:75.
+//   k_direct         direct lighting, one lane per (vertex, light sample); non-zero samples enter the shadow queue.
+//   k_trace_closest  closest hit for continuation rays.
+//   k_trace_shadow   shadow queue (persistent grid): the distance-equality visibility of Scene.cpp:75.
 //   k_accumulate     per pass: framebuffer[m] += rgb/spp in sample order (Renderer.cpp:80).
 //
 // Reference logic covered: Renderer.cpp:39-80, Scene.cpp:19-37,56-184, BVH.cpp:95-135,
 // Bounds3.hpp:95-108, Triangle.hpp:71-76,193-196,222-252, Sphere.hpp:26-48, Material.hpp:26-408.
+#include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 
 #include "mcpt_kernels.h"
 
@@ -108,6 +111,8 @@ struct TraceState {
 #endif
 };
 
+// (A while-while variant -- descend until every lane holds a leaf, then test leaves together -- was measured
+// 10-15 % slower on the chess scene and 5-10 % faster on the Cornell box; the simple loop is kept.)
 template <int MODE, int STK>
 MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, TraceState &st) {
     const float margin = dist * 1e-4f + 1e-2f;
@@ -223,36 +228,31 @@ MCPT_DI uint4 pack_hit(double t, int32_t prim) {
     return make_uint4((uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)prim, 0u);
 }
 
-template <bool SHADOW, int STK>
-__global__ __launch_bounds__(kBlock) void k_trace(DevScene S, uint32_t n, const float4 *__restrict__ ray_o,
-                                                  const float4 *__restrict__ ray_d, uint4 *__restrict__ hit,
-                                                  int32_t n_dir, const float4 *__restrict__ sh_org,
-                                                  const float4 *__restrict__ sh_dir, float *__restrict__ contrib) {
+template <int STK>
+__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n, const float4 *__restrict__ ray_o,
+                                                          const float4 *__restrict__ ray_d, uint4 *__restrict__ hit) {
     __shared__ int32_t stk[STK][kBlock];
     const int tid = threadIdx.x;
     const uint32_t i = blockIdx.x * kBlock + tid;
     if (i >= n) return;
-    f3 o, d;
-    float dist = 0.f;
-    if (SHADOW) {
-        // A light sample whose contribution is exactly +-0 (Dirac BSDFs away from the mirror direction, back-facing
-        // configurations: Material.hpp:338,356,382,397) adds nothing to l_dir whether it is visible or not
-        // (Scene.cpp:76-79), so its shadow ray is not traced.  A NaN contribution is not zero and is traced.
-        if (contrib[i] == 0.f) return;
-        const float4 dd = sh_dir[i];
-        o = ld3(sh_org[i / (uint32_t)n_dir]);
-        d = ld3(dd);
-        dist = dd.w;
-    } else {
-        o = ld3(ray_o[i]);
-        d = ld3(ray_d[i]);
-    }
-    const Ray r = make_ray(o, d);
-    const TraceResult tr = traverse<SHADOW, STK>(S, r, dist, stk, tid);
-    if (SHADOW) {
-        if (!tr.visible) contrib[i] = 0.f;
-    } else {
-        hit[i] = pack_hit(tr.t, tr.prim);
+    const Ray r = make_ray(ld3(ray_o[i]), ld3(ray_d[i]));
+    const TraceResult tr = traverse<false, STK>(S, r, 0.f, stk, tid);
+    hit[i] = pack_hit(tr.t, tr.prim);
+}
+
+// Shadow queue consumer: a fixed grid strides over the queue, whose length is only known on the device.
+template <int STK>
+__global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Counters *__restrict__ counters,
+                                                         const float4 *__restrict__ shq_o, const float4 *__restrict__ shq_d,
+                                                         float *__restrict__ contrib) {
+    __shared__ int32_t stk[STK][kBlock];
+    const int tid = threadIdx.x;
+    const uint32_t n = counters->n_shadow.v;
+    for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += gridDim.x * kBlock) {
+        const float4 o = shq_o[i], d = shq_d[i];
+        const Ray r = make_ray(ld3(o), ld3(d));
+        const TraceResult tr = traverse<true, STK>(S, r, d.w, stk, tid);
+        if (!tr.visible) contrib[__float_as_uint(o.w)] = 0.f;  // Scene.cpp:74-79: an invisible sample adds nothing
     }
 }
 
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
     }
 }
 
-// mcpt_cast_rays: caller-supplied rays, one fresh record per ray; the rays are traced by k_trace<false>.
+// mcpt_cast_rays: caller-supplied rays, one fresh record per ray; the rays are traced by k_trace_closest.
 __global__ __launch_bounds__(kBlock) void k_generate_explicit(Wave next, Counters *c, int next_idx, uint32_t n) {
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
     if (j == 0) {
@@ -407,6 +407,7 @@ __global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Coun
         c->n_paths[0].v = c->n_paths[1].v = 0;
         c->n_rays[0].v = c->n_rays[1].v = 0;
         c->n_free.v = pool;
+        c->n_shadow.v = 0;
         c->pushes.v = 0;
         c->overflow.v = 0;
     }
@@ -482,7 +483,7 @@ MCPT_DI float unwind(const RenderConst &C, uint32_t slot, uint32_t depth, float 
     return X;
 }
 
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wave cur, Wave next, int cur_idx) {
+__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wave cur, Wave next, Scratch Xs, int cur_idx) {
     __shared__ BlockAllocShared sh;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t n_cur = C.counters->n_paths[cur_idx].v;  // the grid is an upper bound; the list length lives on the device
@@ -622,24 +623,10 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wav
     const float kr = mat_fresnel(m, rd, mfn, ch);    // Scene.cpp:110
     const f3 q = p + n * kEps;                       // Scene.cpp:114
     const bool inside = dot(wo, n) < 0;              // Scene.cpp:115
-    next.sh_org[j] = make_float4(q.x, q.y, q.z, 0.f);
-    for (int k = 0; k < C.n_dir; ++k) {              // Scene::directLighting, Scene.cpp:56-82
-        float u[4];
-        rng_block(key, depth, 1u + (uint32_t)k, u);
-        f3 x_l = mk3(0, 0, 0), n_l = mk3(0, 0, 0), emit3 = mk3(0, 0, 0);
-        float pdf = 0.f;
-        float c = 0.f;
-        f3 ws = mk3(0, 0, 1);
-        float dist = 0.f;
-        if (sample_light(S, u, x_l, n_l, emit3, pdf)) {
-            const float emit = comp(emit3, ch);
-            ws = normalized(x_l - q);
-            dist = norm(x_l - q);
-            c = emit * mat_eval(m, ws, wo, n, ch, uv, !inside) * (dot(ws, n)) * dot(-ws, n_l) / (dist * dist) / pdf / C.n_dir;
-        }
-        next.sh_dir[(size_t)j * C.n_dir + k] = make_float4(ws.x, ws.y, ws.z, dist);
-        next.contrib[(size_t)j * C.n_dir + k] = c;
-    }
+    // vertex record for k_direct (Scene::directLighting runs there, one lane per light sample)
+    Xs.vtx0[j] = make_float4(q.x, q.y, q.z, uv.x);
+    Xs.vtx1[j] = make_float4(n.x, n.y, n.z, uv.y);
+    Xs.vtx2[j] = make_float4(wo.x, wo.y, wo.z, __uint_as_float((uint32_t)mat_id | ((uint32_t)ch << 16) | (inside ? (1u << 18) : 0u)));
 
     const bool isReflect = u0[3] < kr;  // Scene.cpp:123
     f3 p2;
@@ -664,6 +651,60 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wav
     }
     next.rec0[j] = make_uint4(pid, rj, flags, __float_as_uint(kr));
     next.rec1[j] = make_float4(ev, aw, pd, __uint_as_float(slot));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_direct: Scene::directLighting (Scene.cpp:56-82), one lane per (shaded vertex, light sample).
+//   c = emit * eval(ws, wo, n) * (ws.n) * (-ws.n_light) / dist^2 / pdf / n_dir_sample          (Scene.cpp:76-79)
+// is stored in contrib[]; samples with c != 0 go to the shadow queue.  A sample whose contribution is exactly
+// +-0 (Dirac BSDFs away from the mirror direction, back-facing configurations: Material.hpp:338,356,382,397)
+// adds nothing to l_dir whether it is visible or not, so it casts no shadow ray; a NaN contribution is not zero
+// and is traced.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wave next, Scratch Xs, uint32_t n_records) {
+    __shared__ BlockAllocShared sh;
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n_dir = (uint32_t)C.n_dir;
+    const bool valid = g < n_records * n_dir;
+    bool cast = false;
+    f3 q = mk3(0, 0, 0), ws = mk3(0, 0, 1);
+    float dist = 0.f;
+    if (valid) {
+        const uint32_t j = g / n_dir, k = g % n_dir;
+        const float4 v0 = Xs.vtx0[j], v1 = Xs.vtx1[j], v2 = Xs.vtx2[j];
+        const uint4 r0 = next.rec0[j];
+        const uint32_t bits = __float_as_uint(v2.w);
+        const MaterialRec m = S.mats[bits & 0xffffu];
+        const bool inside = (bits >> 18) & 1u;
+        q = ld3(v0);
+        const f3 n = ld3(v1), wo = ld3(v2);
+        const f2 uv{v0.w, v1.w};
+        RngKey key;
+        int ch;
+        path_key(C, r0.x, key, ch);
+        float u[4];
+        rng_block(key, r0.z & 0xffffu, 1u + k, u);
+        f3 x_l = mk3(0, 0, 0), n_l = mk3(0, 0, 0), emit3 = mk3(0, 0, 0);
+        float pdf = 0.f, c = 0.f;
+        if (sample_light(S, u, x_l, n_l, emit3, pdf)) {
+            const float emit = comp(emit3, ch);
+            ws = normalized(x_l - q);
+            dist = norm(x_l - q);
+            c = emit * mat_eval(m, ws, wo, n, ch, uv, !inside) * (dot(ws, n)) * dot(-ws, n_l) / (dist * dist) / pdf / C.n_dir;
+        }
+        next.contrib[g] = c;
+        cast = C.enable_shadow && !(c == 0.f);
+    }
+    const bool want[1] = {cast};
+    const uint32_t mult[1] = {1u};
+    uint32_t *const ctr[1] = {&C.counters->n_shadow.v};
+    const bool sub[1] = {false};
+    uint32_t idx[1];
+    block_alloc<1>(sh, want, mult, ctr, sub, idx);
+    if (cast) {
+        Xs.shq_o[idx[0]] = make_float4(q.x, q.y, q.z, __uint_as_float(g));
+        Xs.shq_d[idx[0]] = make_float4(ws.x, ws.y, ws.z, dist);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -711,30 +752,39 @@ void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const
 }
 
 // The LDS stack depth is picked from the scene's tree height (one pushed reference per level at most).
-template <bool SHADOW>
-static void launch_trace(const DevScene &S, uint32_t n, const float4 *ray_o, const float4 *ray_d, uint4 *hit, int32_t n_dir,
-                         const float4 *sh_org, const float4 *sh_dir, float *contrib, hipStream_t s) {
-    const dim3 g(blocks(n)), b(kBlock);
-    if (S.height <= 16) hipLaunchKernelGGL((k_trace<SHADOW, 16>), g, b, 0, s, S, n, ray_o, ray_d, hit, n_dir, sh_org, sh_dir, contrib);
-    else if (S.height <= 24) hipLaunchKernelGGL((k_trace<SHADOW, 24>), g, b, 0, s, S, n, ray_o, ray_d, hit, n_dir, sh_org, sh_dir, contrib);
-    else if (S.height <= 32) hipLaunchKernelGGL((k_trace<SHADOW, 32>), g, b, 0, s, S, n, ray_o, ray_d, hit, n_dir, sh_org, sh_dir, contrib);
-    else hipLaunchKernelGGL((k_trace<SHADOW, kMaxBvhHeight>), g, b, 0, s, S, n, ray_o, ray_d, hit, n_dir, sh_org, sh_dir, contrib);
-}
-
 void launch_trace_closest(const DevScene &S, uint32_t n, const float4 *ray_o, const float4 *ray_d, uint4 *hit, hipStream_t s) {
     if (n == 0) return;
-    launch_trace<false>(S, n, ray_o, ray_d, hit, 1, nullptr, nullptr, nullptr, s);
+    const dim3 g(blocks(n)), b(kBlock);
+    if (S.height <= 16) hipLaunchKernelGGL((k_trace_closest<16>), g, b, 0, s, S, n, ray_o, ray_d, hit);
+    else if (S.height <= 24) hipLaunchKernelGGL((k_trace_closest<24>), g, b, 0, s, S, n, ray_o, ray_d, hit);
+    else if (S.height <= 32) hipLaunchKernelGGL((k_trace_closest<32>), g, b, 0, s, S, n, ray_o, ray_d, hit);
+    else hipLaunchKernelGGL((k_trace_closest<kMaxBvhHeight>), g, b, 0, s, S, n, ray_o, ray_d, hit);
 }
 
-void launch_trace_shadow(const DevScene &S, uint32_t n_rays, int32_t n_dir, const float4 *sh_org, const float4 *sh_dir,
-                         float *contrib, hipStream_t s) {
-    if (n_rays == 0) return;
-    launch_trace<true>(S, n_rays, nullptr, nullptr, nullptr, n_dir, sh_org, sh_dir, contrib, s);
+void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, uint32_t n_records, hipStream_t s) {
+    if (n_records == 0) return;
+    hipLaunchKernelGGL(k_direct, dim3(blocks(n_records * (uint32_t)C.n_dir)), dim3(kBlock), 0, s, S, C, next, X, n_records);
 }
 
-void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, int cur_idx, uint32_t n_cur_max, hipStream_t s) {
+void launch_trace_shadow(const DevScene &S, const Counters *counters, uint32_t n_max, Scratch X, float *contrib, hipStream_t s) {
+    if (n_max == 0) return;
+    // The queue length is only known on the device.  The grid covers the upper bound (capped at 1024 workgroups per
+    // CU, far more than are resident, so the hardware balances uneven rays dynamically: a persistent 8-per-CU grid
+    // was 30 % slower on the Cornell box); workgroups past the end of the queue exit at once, longer queues stride.
+    const int stk = S.height <= 16 ? 16 : (S.height <= 24 ? 24 : (S.height <= 32 ? 32 : kMaxBvhHeight));
+    const char *cap_env = std::getenv("MCPT_SHADOW_GRID_PER_CU");
+    const uint32_t per_cu = cap_env ? (uint32_t)std::max(1, std::atoi(cap_env)) : 1024u;
+    const dim3 g(std::min<uint32_t>(blocks(n_max), 256u * per_cu)), b(kBlock);
+    if (stk == 16) hipLaunchKernelGGL((k_trace_shadow<16>), g, b, 0, s, S, counters, X.shq_o, X.shq_d, contrib);
+    else if (stk == 24) hipLaunchKernelGGL((k_trace_shadow<24>), g, b, 0, s, S, counters, X.shq_o, X.shq_d, contrib);
+    else if (stk == 32) hipLaunchKernelGGL((k_trace_shadow<32>), g, b, 0, s, S, counters, X.shq_o, X.shq_d, contrib);
+    else hipLaunchKernelGGL((k_trace_shadow<kMaxBvhHeight>), g, b, 0, s, S, counters, X.shq_o, X.shq_d, contrib);
+}
+
+void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, Scratch X, int cur_idx, uint32_t n_cur_max,
+                  hipStream_t s) {
     if (n_cur_max == 0) return;
-    hipLaunchKernelGGL(k_shade, dim3(blocks(n_cur_max)), dim3(kBlock), 0, s, S, C, cur, next, cur_idx);
+    hipLaunchKernelGGL(k_shade, dim3(blocks(n_cur_max)), dim3(kBlock), 0, s, S, C, cur, next, X, cur_idx);
 }
 
 void launch_accumulate(const float *result, const uint32_t *pixel_list, uint32_t n_pix, int32_t s_pass, float spp_total,

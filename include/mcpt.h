@@ -107,13 +107,15 @@ typedef struct {
     uint64_t vertices;      /* Scene::castRay invocations the reference would execute (Scene.cpp:85) */
     uint64_t shaded;        /* vertices that reached Material::sample (Scene.cpp:109) */
     uint64_t closest_rays;  /* closest-hit rays actually traced (primary once per sample + continuations) */
-    uint64_t shadow_rays;   /* shadow rays actually traced */
+    uint64_t shadow_rays;   /* shadow rays actually traced (light samples with a non-zero contribution) */
     uint64_t ref_scene_rays;/* Scene::intersect calls the reference would make for the same work */
     uint64_t iterations;    /* wavefront iterations */
     uint64_t overflow_paths;/* paths cut by max_depth */
     double ms_total;        /* wall time of the call, host clock */
     double ms_trace_closest, ms_trace_shadow, ms_shade, ms_generate, ms_resolve; /* HIP-event sums per kernel class */
     uint64_t n_trace_closest, n_trace_shadow, n_shade, n_generate, n_resolve;    /* launches per kernel class */
+    double ms_direct;   /* k_direct (direct-lighting kernel) */
+    uint64_t n_direct;
 } mcpt_stats;
 
 typedef struct mcpt_scene mcpt_scene;
