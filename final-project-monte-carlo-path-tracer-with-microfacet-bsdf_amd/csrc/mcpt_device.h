@@ -113,20 +113,34 @@ MCPT_DI Ray make_ray(f3 o, f3 d) {
 
 // Bounds3::IntersectP, Bounds3.hpp:95-108.  fmin/fmax ignore a NaN operand; the initializer-list
 // std::max/std::min keep a NaN that sits in the x slot.
+// FAST: the caller guarantees that the ray's three reciprocals are finite.  Box corners and the origin are finite,
+// so every slab product is then finite or +-inf (overflow) and no NaN exists; on NaN-free inputs the chained
+// compare/selects of the reference equal plain max/min, which compile to v_max3_f32 / v_min3_f32.
+template <bool FAST>
 MCPT_DI bool box_hit(const float mn[3], const float mx[3], const Ray &r, float &tmin_out, float &tmax_out) {
     const float t1x = (mn[0] - r.o.x) * r.inv.x, t1y = (mn[1] - r.o.y) * r.inv.y, t1z = (mn[2] - r.o.z) * r.inv.z;
     const float t2x = (mx[0] - r.o.x) * r.inv.x, t2y = (mx[1] - r.o.y) * r.inv.y, t2z = (mx[2] - r.o.z) * r.inv.z;
     const float lx = fminf(t1x, t2x), ly = fminf(t1y, t2y), lz = fminf(t1z, t2z);
     const float hx = fmaxf(t1x, t2x), hy = fmaxf(t1y, t2y), hz = fmaxf(t1z, t2z);
-    float tmin = lx;
-    if (tmin < ly) tmin = ly;
-    if (tmin < lz) tmin = lz;
-    float tmax = hx;
-    if (hy < tmax) tmax = hy;
-    if (hz < tmax) tmax = hz;
+    float tmin, tmax;
+    if (FAST) {
+        tmin = fmaxf(fmaxf(lx, ly), lz);
+        tmax = fminf(fminf(hx, hy), hz);
+    } else {
+        tmin = lx;
+        if (tmin < ly) tmin = ly;
+        if (tmin < lz) tmin = lz;
+        tmax = hx;
+        if (hy < tmax) tmax = hy;
+        if (hz < tmax) tmax = hz;
+    }
     tmin_out = tmin;
     tmax_out = tmax;
     return (tmin - kEps <= tmax) && (tmax >= -kEps);
+}
+
+MCPT_DI bool ray_is_plain(const Ray &r) {  // all three reciprocals finite (no zero / denormal direction component)
+    return (fabsf(r.inv.x) < INFINITY) && (fabsf(r.inv.y) < INFINITY) && (fabsf(r.inv.z) < INFINITY);
 }
 
 // Triangle::getIntersection, Triangle.hpp:222-252 (two-sided Moller-Trumbore, double det chain).

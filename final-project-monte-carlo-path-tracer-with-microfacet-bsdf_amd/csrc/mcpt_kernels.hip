@@ -113,13 +113,13 @@ struct TraceState {
 
 // (A while-while variant -- descend until every lane holds a leaf, then test leaves together -- was measured
 // 10-15 % slower on the chess scene and 5-10 % faster on the Cornell box; the simple loop is kept.)
-template <int MODE, int STK>
+template <int MODE, int STK, bool FAST>
 MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, TraceState &st) {
     const float margin = dist * 1e-4f + 1e-2f;
     float lim = (MODE == kClosest) ? INFINITY : (dist + margin);
     const float lo = dist - margin;
     float tm, tx;
-    if (!box_hit(S.root_min, S.root_max, r, tm, tx)) return;
+    if (!box_hit<FAST>(S.root_min, S.root_max, r, tm, tx)) return;
     int32_t cur = S.root;
     int sp = 0;
     while (true) {
@@ -135,8 +135,9 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
             const float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
             const int32_t left = __float_as_int(e.x), right = __float_as_int(e.y);
             float tl = 0.f, tr = 0.f, txl = 0.f, txr = 0.f;
-            bool hl = (left != kNoChild) && box_hit(lmin, lmax, r, tl, txl);
-            bool hr = (right != kNoChild) && box_hit(rmin, rmax, r, tr, txr);
+            // every inner node has two children (the builder only emits an inner node for >= 2 primitives)
+            bool hl = box_hit<FAST>(lmin, lmax, r, tl, txl);
+            bool hr = box_hit<FAST>(rmin, rmax, r, tr, txr);
             hl = hl && !(tl > lim);
             hr = hr && !(tr > lim);
             if (MODE == kWindow) {
@@ -199,13 +200,23 @@ MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_
 #ifdef MCPT_TRAVERSAL_STATS
     st.nv = st.nt = st.iters = 0;
 #endif
+    // Wave-uniform choice of the slab-test flavour: the exact NaN-faithful chain only when some lane of the wave
+    // has a non-finite reciprocal (a zero direction component); otherwise the bit-identical max3/min3 form.
+    const bool plain = __all(ray_is_plain(r)) != 0;
     if (SHADOW) {
         // Scene.cpp:74-75: a light sample counts iff the CLOSEST hit lies within EPSILON of the light distance,
         // i.e. iff some hit lies in the window AND no hit lies at or below dist - EPSILON.
-        traverse_loop<kWindow, STK>(S, r, dist, stk, tid, st);
-        if (st.found && !st.occluded) traverse_loop<kOccluder, STK>(S, r, dist, stk, tid, st);
+        if (plain) {
+            traverse_loop<kWindow, STK, true>(S, r, dist, stk, tid, st);
+            if (st.found && !st.occluded) traverse_loop<kOccluder, STK, true>(S, r, dist, stk, tid, st);
+        } else {
+            traverse_loop<kWindow, STK, false>(S, r, dist, stk, tid, st);
+            if (st.found && !st.occluded) traverse_loop<kOccluder, STK, false>(S, r, dist, stk, tid, st);
+        }
+    } else if (plain) {
+        traverse_loop<kClosest, STK, true>(S, r, dist, stk, tid, st);
     } else {
-        traverse_loop<kClosest, STK>(S, r, dist, stk, tid, st);
+        traverse_loop<kClosest, STK, false>(S, r, dist, stk, tid, st);
     }
 #ifdef MCPT_TRAVERSAL_STATS
     if (S.dbg) {  // [kind*8 + {rays, node visits, prim tests, occluded/hit, wave-iterations*64, found}]

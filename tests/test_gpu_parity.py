@@ -42,6 +42,32 @@ def test_intersect_bit_exact(pkg, oracle, hip, name):
     assert (p_ref >= 0).mean() > 0.3
 
 
+def test_intersect_degenerate_directions(pkg, oracle, hip):
+    """Axis-aligned, zero-component and all-zero directions (Material::refract returns (0,0,0) on total internal
+    reflection): the reciprocals are +-inf and the slab test meets inf/NaN.  Bounds3::IntersectP's NaN behaviour
+    (fmin/fmax ignore NaN, std::max({..}) keeps a NaN in the x slot) must be reproduced bit for bit."""
+    sd = pkg.scenes.cornell_demo(64, 64, 4)
+    os_, hs = oracle.OracleScene(sd), hip.HipScene(sd)
+    rng = np.random.default_rng(5)
+    n = 6000
+    o = rng.uniform(-50, 600, size=(n, 3)).astype(np.float32)
+    o[::7, 0] = 0.0        # on the x = 0 wall plane
+    o[1::7, 1] = 548.8     # on the ceiling plane
+    o[2::7, 2] = 559.2     # on the back wall plane
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    axes = np.eye(3, dtype=np.float32)
+    d[0::5] = axes[rng.integers(0, 3, size=len(d[0::5]))] * rng.choice([-1, 1], size=(len(d[0::5]), 1)).astype(np.float32)
+    d[1::5, 0] = 0.0       # one zero component (not renormalised: the reference never normalises inside intersect)
+    d[2::25] = 0.0         # all-zero direction
+    d[3::25, 1] = -0.0
+    t_ref, p_ref = os_.intersect(o, d)
+    t_gpu, p_gpu = hs.intersect(o, d)
+    assert np.array_equal(p_ref, p_gpu), "primitive ids differ on %d rays" % int((p_ref != p_gpu).sum())
+    assert np.array_equal(t_ref.view(np.uint64), t_gpu.view(np.uint64))
+    assert (p_ref >= 0).mean() > 0.2
+
+
 def test_camera_rays(pkg, oracle, hip):
     sd = pkg.scenes.chess_scene(width=160, height=90, spp=4)  # DOF on
     os_, hs = oracle.OracleScene(sd), hip.HipScene(sd)
