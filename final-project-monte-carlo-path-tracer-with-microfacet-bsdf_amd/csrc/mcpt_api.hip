@@ -79,7 +79,8 @@ struct Workspace {
     int32_t n_dir = 0, max_depth = 0;
     WaveBufs wave[2];
     DevBuf<float4> vtx0, vtx1, vtx2, shq_o, shq_d;
-    Scratch scratch() const { return Scratch{vtx0.p, vtx1.p, vtx2.p, shq_o.p, shq_d.p}; }
+    DevBuf<uint32_t> vtx_j;
+    Scratch scratch() const { return Scratch{vtx0.p, vtx1.p, vtx2.p, vtx_j.p, shq_o.p, shq_d.p}; }
     DevBuf<float4> stack;
     DevBuf<float> result;
     DevBuf<uint32_t> free_slots, pixel_list, key_pixel, key_sample;
@@ -88,7 +89,7 @@ struct Workspace {
     Counters *h_counters = nullptr;  // pinned
     void release() {
         wave[0].release(); wave[1].release(); stack.release(); result.release(); free_slots.release();
-        vtx0.release(); vtx1.release(); vtx2.release(); shq_o.release(); shq_d.release();
+        vtx0.release(); vtx1.release(); vtx2.release(); vtx_j.release(); shq_o.release(); shq_d.release();
         pixel_list.release(); key_pixel.release(); key_sample.release(); key_channel.release(); counters.release();
         if (h_counters) (void)hipHostFree(h_counters);
         h_counters = nullptr;
@@ -185,6 +186,7 @@ hipError_t ensure_workspace(mcpt_scene *sc, uint32_t pool, int32_t n_dir, int32_
     if ((e = w.vtx0.alloc(pool)) != hipSuccess) return e;
     if ((e = w.vtx1.alloc(pool)) != hipSuccess) return e;
     if ((e = w.vtx2.alloc(pool)) != hipSuccess) return e;
+    if ((e = w.vtx_j.alloc(pool)) != hipSuccess) return e;
     if ((e = w.shq_o.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
     if ((e = w.shq_d.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
     if ((e = w.stack.alloc((size_t)pool * max_depth)) != hipSuccess) return e;
@@ -242,7 +244,7 @@ void build_pixel_list(int W, int H, int tile, int rank, int nranks, std::vector<
 }
 
 struct LoopTotals {
-    uint64_t iterations = 0, shaded = 0, closest = 0, shadow = 0;
+    uint64_t iterations = 0, shaded = 0, closest = 0, shadow = 0, direct = 0;
 };
 
 // Runs the wavefront loop until `n_work` units (camera samples in mode 0, explicit paths in mode 1) are
@@ -287,6 +289,7 @@ int run_wavefront(mcpt_scene *sc, const RenderConst &C0, const CameraConst *cam,
         Wave cw = w.wave[cur].view(), nx = w.wave[nxt].view();
         HIP_TRY(hipMemsetAsync(&w.counters.p->n_paths[nxt], 0, sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(&w.counters.p->n_rays[nxt], 0, sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(&w.counters.p->n_direct, 0, sizeof(uint32_t), st));
         int ev = T.begin(st);
         launch_shade(sc->view, C, cw, nx, w.scratch(), cur, n_cur_max, st);
         T.end(ev, K_SHADE, st);
@@ -294,7 +297,8 @@ int run_wavefront(mcpt_scene *sc, const RenderConst &C0, const CameraConst *cam,
         HIP_TRY(hipStreamSynchronize(st));
         T.collect();
         const uint32_t n_next = w.h_counters->n_paths[nxt].v, n_cont = w.h_counters->n_rays[nxt].v;
-        const uint32_t n_free = w.h_counters->n_free.v;
+        const uint32_t n_free = w.h_counters->n_free.v, n_direct = w.h_counters->n_direct.v;
+        tot.direct += n_direct;
         tot.iterations++;
         tot.shaded += n_next;
         tot.shadow += w.h_counters->n_shadow.v;  // shadow queue length of the previous iteration
@@ -306,13 +310,13 @@ int run_wavefront(mcpt_scene *sc, const RenderConst &C0, const CameraConst *cam,
             tot.closest += n_cont;
         }
         HIP_TRY(hipMemsetAsync(&w.counters.p->n_shadow, 0, sizeof(uint32_t), st));
-        if (n_next > 0) {
+        if (n_direct > 0) {
             ev = T.begin(st);
-            launch_direct(sc->view, C, nx, w.scratch(), n_next, st);
+            launch_direct(sc->view, C, nx, w.scratch(), n_direct, st);
             T.end(ev, K_DIRECT, st);
             if (C.enable_shadow) {
                 ev = T.begin(st);
-                launch_trace_shadow(sc->view, w.counters.p, n_next * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
+                launch_trace_shadow(sc->view, w.counters.p, n_direct * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
                 T.end(ev, K_SHADOW, st);
             }
         }
@@ -416,6 +420,7 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
         stats->shaded = tot.shaded;
         stats->closest_rays = tot.closest;
         stats->shadow_rays = tot.shadow;
+        stats->direct_vertices = tot.direct;
         // Scene::intersect calls of the reference: one per castRay invocation (Scene.cpp:87), n_dir per shaded
         // vertex (Scene.cpp:73), one look-ahead per vertex that survives roulette (Scene.cpp:134,161).
         const uint64_t cont = tot.closest - stats->samples;
@@ -506,8 +511,10 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
     v.env_w = hs.env_w;
     v.env_h = hs.env_h;
     v.height = hs.height;
+    for (int k = 0; k < 3; ++k) v.light_center[k] = hs.light_center[k];
+    v.light_radius = hs.light_radius;
     v.dbg = nullptr;
-#ifdef MCPT_TRAVERSAL_STATS
+#if defined(MCPT_TRAVERSAL_STATS) || defined(MCPT_CHECK_DIRECT_SKIP)
     if (sc->dbg.alloc(16) == hipSuccess) {
         (void)hipMemset(sc->dbg.p, 0, 16 * sizeof(unsigned long long));
         v.dbg = sc->dbg.p;
@@ -527,10 +534,11 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
 void mcpt_scene_destroy(mcpt_scene *sc) {
     if (!sc) return;
     (void)hipSetDevice(sc->device);
-#ifdef MCPT_TRAVERSAL_STATS
+#if defined(MCPT_TRAVERSAL_STATS) || defined(MCPT_CHECK_DIRECT_SKIP)
     if (sc->dbg.p) {
         unsigned long long h[16];
         if (hipMemcpy(h, sc->dbg.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (h[14]) std::fprintf(stderr, "[mcpt direct-skip check] light samples at skipped vertices: %llu, non-zero contributions among them: %llu\n", h[14], h[15]);
             for (int k = 0; k < 2; ++k) {
                 const unsigned long long *d = h + 8 * k;
                 if (!d[0]) continue;

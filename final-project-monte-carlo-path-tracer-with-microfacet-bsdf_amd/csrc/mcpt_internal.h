@@ -113,6 +113,8 @@ struct HostScene {
     int32_t env_w = 0, env_h = 0;
     std::vector<float> env;
     float light_area_sum = 0.f;
+    float light_center[3] = {0.f, 0.f, 0.f};  // bounding sphere of every emissive primitive
+    float light_radius = 0.f;
 };
 
 // Builds the flattened scene.  Returns MCPT_OK or an error code and fills `err`.

@@ -10,6 +10,7 @@ namespace mcpt {
 constexpr uint32_t kFresh = 1u << 16;      // no pending vertex: the record's ray is the path's first ray
 constexpr uint32_t kTerminate = 1u << 17;  // Russian roulette failed at the pending vertex (Scene.cpp:129,156)
 constexpr uint32_t kInside = 1u << 18;     // wo.n < 0 at the pending vertex (Scene.cpp:115)
+constexpr uint32_t kNoDirect = 1u << 19;   // every light sample of the pending vertex contributes exactly 0: contrib[] not written
 
 // Device counters.  Every hot word sits on its own 128-byte line: the allocation atomics of different
 // queues then never serialise on one L2 line / memory channel.
@@ -21,6 +22,7 @@ struct Counters {
     HotCounter n_paths[2];  // records in path list 0 / 1
     HotCounter n_rays[2];   // entries in closest-hit queue 0 / 1
     HotCounter n_shadow;    // entries in the shadow-ray queue of the current iteration
+    HotCounter n_direct;    // vertices of the current iteration that need direct lighting (k_direct work list)
     HotCounter n_free;      // entries in the free-slot stack
     HotCounter pushes;      // cumulative: recursion levels entered (castRay depth+1 calls)
     HotCounter overflow;    // cumulative: paths cut by max_depth
@@ -39,9 +41,10 @@ struct Wave {
 // Per-iteration scratch between k_shade, k_direct and k_trace<shadow> (single-buffered: produced and consumed
 // inside one iteration).
 struct Scratch {
-    float4 *vtx0;   // per record of the next list: {q.xyz (offset shading point, Scene.cpp:114), uv.x}
+    float4 *vtx0;   // k_direct work list: {q.xyz (offset shading point, Scene.cpp:114), uv.x}
     float4 *vtx1;   // {n.xyz, uv.y}
     float4 *vtx2;   // {wo.xyz, bits: material | channel << 16 | inside << 18}
+    uint32_t *vtx_j;  // index of the vertex's record in the next path list
     float4 *shq_o;  // compacted shadow queue: {origin.xyz, bits: index into contrib}
     float4 *shq_d;  // {direction.xyz, distance to the light sample}
 };
@@ -80,9 +83,9 @@ void launch_generate_explicit(const RenderConst &C, Wave next, int next_idx, uin
 void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const uint32_t *pixel, const uint32_t *sample,
                         float4 *o, float4 *d, hipStream_t s);
 void launch_trace_closest(const DevScene &S, uint32_t n, const float4 *ray_o, const float4 *ray_d, uint4 *hit, hipStream_t s);
-// Direct lighting (Scene::directLighting, Scene.cpp:56-82) for the n_records vertices shaded into `next`:
+// Direct lighting (Scene::directLighting, Scene.cpp:56-82) for the n_vertices entries of the k_direct work list:
 // one lane per (vertex, light sample); fills next.contrib and appends the non-zero samples to the shadow queue.
-void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, uint32_t n_records, hipStream_t s);
+void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, uint32_t n_vertices, hipStream_t s);
 // Shadow queue (length in counters->n_shadow, at most n_max): zeroes contrib[] of invisible samples.
 void launch_trace_shadow(const DevScene &S, const Counters *counters, uint32_t n_max, Scratch X, float *contrib, hipStream_t s);
 // Shades list `cur_idx` (at most n_cur_max records; the true count is read from the device counter) into the other list.

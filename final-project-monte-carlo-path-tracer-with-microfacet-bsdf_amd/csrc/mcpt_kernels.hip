@@ -419,6 +419,7 @@ __global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Coun
         c->n_rays[0].v = c->n_rays[1].v = 0;
         c->n_free.v = pool;
         c->n_shadow.v = 0;
+        c->n_direct.v = 0;
         c->pushes.v = 0;
         c->overflow.v = 0;
     }
@@ -476,6 +477,53 @@ MCPT_DI bool sample_light(const DevScene &S, const float u[4], f3 &x_l, f3 &n_l,
 }
 
 // ------------------------------------------------------------------------------------------------
+// direct_is_zero: true only if EVERY light sample at this vertex has eval() == 0 exactly, so that
+// Scene::directLighting (Scene.cpp:56-82) returns +0 whatever the draws and the visibilities are.
+//   * no emitter in the scene;
+//   * a conductor seen from inside: directLighting is called with isReflect = false (Scene.cpp:115-116) and
+//     eval(.., false) returns 0 for both conductor types (Material.hpp:355-357,396-399);
+//   * a Dirac BSDF (Material.hpp:375-403) is non-zero only if h.N >= 1 - EPSILON, i.e. the half vector lies within
+//     acos(1 - 1e-4) = 0.01414 rad of N.  Reflection: ws then lies within 2 * 0.01414 rad of the mirror direction
+//     r = 2 (N.wo) N - wo.  Refraction (dielectric seen from inside, ws outside): ws = -ior*wo - lambda*h, so it
+//     lies within |lambda| * 0.01414 / cos(theta_i) <= 0.094 rad of the Snell direction when ior * sin(theta_o) <= 0.9.
+//     Every light sample lies inside the cone of half-angle asin(R / D) around the direction to the centre of the
+//     emitters' bounding sphere (radius R, distance D > 1.01 R).  If r is farther from that cone than the tolerance
+//     (0.06 rad for reflection, 0.15 rad for refraction: > 1.5x the bounds above) no sample can give a non-zero eval.
+// tests: the -DMCPT_CHECK_DIRECT_SKIP build evaluates the skipped vertices anyway and counts non-zero contributions.
+// ------------------------------------------------------------------------------------------------
+MCPT_DI bool direct_is_zero(const DevScene &S, const MaterialRec &m, f3 q, f3 n, f3 wo, bool inside, int ch) {
+    if (S.n_lights == 0) return true;
+    const bool conductor = (m.type == MCPT_SMOOTH_CONDUCTOR || m.type == MCPT_ROUGH_CONDUCTOR);
+    if (inside && conductor) return true;
+    if (!m.isDirac) return false;
+    const f3 L = mk3(S.light_center[0], S.light_center[1], S.light_center[2]) - q;
+    const float D2 = dot(L, L), R = S.light_radius;
+    if (!(D2 > R * R * 1.0201f)) return false;
+    const float D = sqrtf(D2);
+    const float sl = R / D, cl = sqrtf(1.0f - sl * sl);
+    f3 r;
+    float cm, sm;
+    if (!inside) {
+        r = n * (2 * dot(n, wo)) - wo;
+        cm = 0.99820054f;  // cos(0.06)
+        sm = 0.05996400f;  // sin(0.06)
+    } else {
+        const float ior = get_ior(m, ch);
+        const float won = dot(wo, n);
+        const f3 wot = wo - n * won;
+        const float sin2 = ior * ior * dot(wot, wot);
+        if (!(sin2 < 0.81f)) return false;
+        r = wot * (-ior) + n * sqrtf(1.0f - sin2);
+        cm = 0.98877108f;  // cos(0.15)
+        sm = 0.14943813f;  // sin(0.15)
+    }
+    const float rl = norm(r);
+    if (!(rl > 0.5f && rl < 2.0f)) return false;
+    const float cos_a = dot(r, L) / (rl * D);
+    return cos_a < (cl * cm - sl * sm) - 1e-3f;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_shade: Scene::castRay (Scene.cpp:85-184) turned inside out.
 //
 // The recursion  L_d = clamp(0,15,l_dir_d) + clamp(0,5, L_{d+1} * f_d)  is not multiplicative (per-level
@@ -522,7 +570,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wav
         if (!(flags & kFresh)) {
             // ---- resolve the pending vertex: Scene.cpp:114-119 (l_dir), 129-149 / 156-176 (l_ind)
             float dl = 0.f;
-            for (int k = 0; k < C.n_dir; ++k) dl += cur.contrib[(size_t)i * C.n_dir + k];  // Scene.cpp:76 `l_dir +=`, in order
+            if (!(flags & kNoDirect))
+                for (int k = 0; k < C.n_dir; ++k) dl += cur.contrib[(size_t)i * C.n_dir + k];  // Scene.cpp:76 `l_dir +=`, in order
             const float kr = __uint_as_float(r0.w);
             const float l_dir = (flags & kInside) ? (float)((1. - (double)kr) * (double)dl) : kr * dl;
             if (flags & kTerminate) {
@@ -614,37 +663,49 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wav
     if (do_shade) rng_block(key, depth, 0u, u0);
     const bool has_cont = do_shade && !(u0[2] >= C.rr_rate);  // Scene.cpp:121,129,156
 
-    // one round of block-aggregated atomics: released slots, next-list records, continuation rays, statistics
-    uint32_t j, rj;
+    const f3 q = p + n * kEps;                       // Scene.cpp:114
+    const bool inside = dot(wo, n) < 0;              // Scene.cpp:115
+    const bool zero_direct = do_shade && direct_is_zero(S, m, q, n, wo, inside, ch);
+#ifdef MCPT_CHECK_DIRECT_SKIP
+    const bool need_direct = do_shade;  // checking build: evaluate the skipped vertices too (k_direct counts violations)
+#else
+    const bool need_direct = do_shade && !zero_direct;
+#endif
+
+    // one round of block-aggregated atomics: released slots, next-list records, continuation rays, the direct-
+    // lighting work list, statistics
+    uint32_t j, rj, dj;
     {
-        const bool want[5] = {finished, do_shade, has_cont, pushed, overflow};
-        const uint32_t mult[5] = {1u, 1u, 1u, 1u, 1u};
-        uint32_t *const ctr[5] = {&C.counters->n_free.v, &C.counters->n_paths[next_idx].v, &C.counters->n_rays[next_idx].v,
-                                  &C.counters->pushes.v, &C.counters->overflow.v};
-        const bool sub[5] = {false, false, false, false, false};
-        uint32_t idx[5];
-        block_alloc<5>(sh, want, mult, ctr, sub, idx);
+        const bool want[6] = {finished, do_shade, has_cont, need_direct, pushed, overflow};
+        const uint32_t mult[6] = {1u, 1u, 1u, 1u, 1u, 1u};
+        uint32_t *const ctr[6] = {&C.counters->n_free.v, &C.counters->n_paths[next_idx].v, &C.counters->n_rays[next_idx].v,
+                                  &C.counters->n_direct.v, &C.counters->pushes.v, &C.counters->overflow.v};
+        const bool sub[6] = {false, false, false, false, false, false};
+        uint32_t idx[6];
+        block_alloc<6>(sh, want, mult, ctr, sub, idx);
         if (finished) C.free_slots[idx[0]] = slot;
         j = idx[1];
         rj = idx[2];
+        dj = idx[3];
     }
     if (!do_shade) return;
 
     const f3 mfn = mat_sample(m, n, u0[0], u0[1]);   // Scene.cpp:109
     const float kr = mat_fresnel(m, rd, mfn, ch);    // Scene.cpp:110
-    const f3 q = p + n * kEps;                       // Scene.cpp:114
-    const bool inside = dot(wo, n) < 0;              // Scene.cpp:115
-    // vertex record for k_direct (Scene::directLighting runs there, one lane per light sample)
-    Xs.vtx0[j] = make_float4(q.x, q.y, q.z, uv.x);
-    Xs.vtx1[j] = make_float4(n.x, n.y, n.z, uv.y);
-    Xs.vtx2[j] = make_float4(wo.x, wo.y, wo.z, __uint_as_float((uint32_t)mat_id | ((uint32_t)ch << 16) | (inside ? (1u << 18) : 0u)));
+    if (need_direct) {  // work-list entry for k_direct (Scene::directLighting runs there, one lane per light sample)
+        Xs.vtx0[dj] = make_float4(q.x, q.y, q.z, uv.x);
+        Xs.vtx1[dj] = make_float4(n.x, n.y, n.z, uv.y);
+        Xs.vtx2[dj] = make_float4(wo.x, wo.y, wo.z, __uint_as_float((uint32_t)mat_id | ((uint32_t)ch << 16) | (inside ? (1u << 18) : 0u) |
+                                                                    (zero_direct ? (1u << 19) : 0u)));
+        Xs.vtx_j[dj] = j;
+    }
 
     const bool isReflect = u0[3] < kr;  // Scene.cpp:123
     f3 p2;
     if (isReflect) p2 = (dot(wo, mfn) < 0) ? (p - n * kEps) : (p + n * kEps);  // Scene.cpp:124-128
     else p2 = (dot(wo, mfn) < 0) ? (p + n * kEps) : (p - n * kEps);            // Scene.cpp:151-155
 
-    uint32_t flags = depth | (inside ? kInside : 0u);
+    uint32_t flags = depth | (inside ? kInside : 0u) | (need_direct ? 0u : kNoDirect);
     float ev = 0.f, aw = 0.f, pd = 0.f;
     if (has_cont) {
         const f3 wi = isReflect ? mat_reflect(wo, mfn) : mat_refract(m, rd, mfn, ch);  // Scene.cpp:132,159
@@ -672,17 +733,20 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wav
 // adds nothing to l_dir whether it is visible or not, so it casts no shadow ray; a NaN contribution is not zero
 // and is traced.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wave next, Scratch Xs, uint32_t n_records) {
+__global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wave next, Scratch Xs, uint32_t n_vertices) {
     __shared__ BlockAllocShared sh;
     const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t n_dir = (uint32_t)C.n_dir;
-    const bool valid = g < n_records * n_dir;
+    const bool valid = g < n_vertices * n_dir;
     bool cast = false;
     f3 q = mk3(0, 0, 0), ws = mk3(0, 0, 1);
     float dist = 0.f;
+    uint32_t target = 0;
     if (valid) {
-        const uint32_t j = g / n_dir, k = g % n_dir;
-        const float4 v0 = Xs.vtx0[j], v1 = Xs.vtx1[j], v2 = Xs.vtx2[j];
+        const uint32_t dj = g / n_dir, k = g % n_dir;
+        const float4 v0 = Xs.vtx0[dj], v1 = Xs.vtx1[dj], v2 = Xs.vtx2[dj];
+        const uint32_t j = Xs.vtx_j[dj];
+        target = j * n_dir + k;
         const uint4 r0 = next.rec0[j];
         const uint32_t bits = __float_as_uint(v2.w);
         const MaterialRec m = S.mats[bits & 0xffffu];
@@ -703,8 +767,14 @@ __global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wa
             dist = norm(x_l - q);
             c = emit * mat_eval(m, ws, wo, n, ch, uv, !inside) * (dot(ws, n)) * dot(-ws, n_l) / (dist * dist) / pdf / C.n_dir;
         }
-        next.contrib[g] = c;
+        next.contrib[target] = c;
         cast = C.enable_shadow && !(c == 0.f);
+#ifdef MCPT_CHECK_DIRECT_SKIP
+        if (((bits >> 19) & 1u) && S.dbg) {
+            atomicAdd(&S.dbg[14], 1ull);
+            if (!(c == 0.f)) atomicAdd(&S.dbg[15], 1ull);
+        }
+#endif
     }
     const bool want[1] = {cast};
     const uint32_t mult[1] = {1u};
@@ -713,7 +783,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wa
     uint32_t idx[1];
     block_alloc<1>(sh, want, mult, ctr, sub, idx);
     if (cast) {
-        Xs.shq_o[idx[0]] = make_float4(q.x, q.y, q.z, __uint_as_float(g));
+        Xs.shq_o[idx[0]] = make_float4(q.x, q.y, q.z, __uint_as_float(target));
         Xs.shq_d[idx[0]] = make_float4(ws.x, ws.y, ws.z, dist);
     }
 }
@@ -772,9 +842,9 @@ void launch_trace_closest(const DevScene &S, uint32_t n, const float4 *ray_o, co
     else hipLaunchKernelGGL((k_trace_closest<kMaxBvhHeight>), g, b, 0, s, S, n, ray_o, ray_d, hit);
 }
 
-void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, uint32_t n_records, hipStream_t s) {
-    if (n_records == 0) return;
-    hipLaunchKernelGGL(k_direct, dim3(blocks(n_records * (uint32_t)C.n_dir)), dim3(kBlock), 0, s, S, C, next, X, n_records);
+void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, uint32_t n_vertices, hipStream_t s) {
+    if (n_vertices == 0) return;
+    hipLaunchKernelGGL(k_direct, dim3(blocks(n_vertices * (uint32_t)C.n_dir)), dim3(kBlock), 0, s, S, C, next, X, n_vertices);
 }
 
 void launch_trace_shadow(const DevScene &S, const Counters *counters, uint32_t n_max, Scratch X, float *contrib, hipStream_t s) {

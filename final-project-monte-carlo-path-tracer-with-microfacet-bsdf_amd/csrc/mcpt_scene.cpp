@@ -440,6 +440,23 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) 
         hs.lights.push_back(L);
         hs.light_area_sum += L.area;  // Scene.cpp:24-27
     }
+    // bounding sphere of all emitters (k_shade's "no light sample can contribute" test)
+    {
+        Box lb = box_empty();
+        for (int oi = 0; oi < d.n_objects; ++oi)
+            if (hs.materials[d.objects[oi].material].hasEmission) lb = box_union(lb, top_objs[oi].bounds);
+        if (!hs.lights.empty()) {
+            const V3 c = centroid(lb);
+            double r2 = 0.0;
+            for (int k = 0; k < 8; ++k) {
+                const double dx = ((k & 1) ? lb.mx.x : lb.mn.x) - (double)c.x, dy = ((k & 2) ? lb.mx.y : lb.mn.y) - (double)c.y,
+                             dz = ((k & 4) ? lb.mx.z : lb.mn.z) - (double)c.z;
+                r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+            }
+            store3(hs.light_center, c);
+            hs.light_radius = (float)(std::sqrt(r2) * 1.001 + 1e-3);
+        }
+    }
     if (light_depth > kMaxLightTreeDepth) {
         *err = "light mesh tree too deep";
         return MCPT_ERR_LIMIT;

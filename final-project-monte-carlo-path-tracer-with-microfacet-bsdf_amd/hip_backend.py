@@ -44,7 +44,7 @@ class Stats(C.Structure):
                 ("ms_trace_closest", C.c_double), ("ms_trace_shadow", C.c_double), ("ms_shade", C.c_double),
                 ("ms_generate", C.c_double), ("ms_resolve", C.c_double),
                 ("n_trace_closest", C.c_uint64), ("n_trace_shadow", C.c_uint64), ("n_shade", C.c_uint64),
-                ("n_generate", C.c_uint64), ("n_resolve", C.c_uint64), ("ms_direct", C.c_double), ("n_direct", C.c_uint64)]
+                ("n_generate", C.c_uint64), ("n_resolve", C.c_uint64), ("ms_direct", C.c_double), ("n_direct", C.c_uint64), ("direct_vertices", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

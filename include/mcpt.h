@@ -116,6 +116,7 @@ typedef struct {
     uint64_t n_trace_closest, n_trace_shadow, n_shade, n_generate, n_resolve;    /* launches per kernel class */
     double ms_direct;   /* k_direct (direct-lighting kernel) */
     uint64_t n_direct;
+    uint64_t direct_vertices; /* shaded vertices whose light samples were evaluated (the rest provably contribute 0) */
 } mcpt_stats;
 
 typedef struct mcpt_scene mcpt_scene;

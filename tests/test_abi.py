@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(hip):
 def test_struct_sizes_match_header(hip, pkg):
     assert C.sizeof(hip.SceneDesc) == 64   # 5 int32 + 3 float + 4 pointers
     assert C.sizeof(hip.Params) == 14 * 4
-    assert C.sizeof(hip.Stats) == 9 * 8 + 6 * 8 + 5 * 8 + 2 * 8
+    assert C.sizeof(hip.Stats) == 9 * 8 + 6 * 8 + 5 * 8 + 3 * 8
     assert C.sizeof(hip.SceneInfo) == 24
 
 
