@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--cpu-spp", type=int, default=12, help="spp of the bounded CPU-baseline sample (full frame)")
     ap.add_argument("--no-psnr", action="store_true")
     ap.add_argument("--save-png", default="")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-device rehearses the N>1 path on a one-GPU box (the reduce goes through host memory)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -94,11 +97,32 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend="gloo")
+
+    def reduce_to_rank0(t):
+        if args.backend == "nccl":
+            dist.reduce(t, dst=0)
+        else:  # rehearsal path
+            h = t.cpu()
+            dist.reduce(h, dst=0)
+            t.copy_(h)
+
+    def allreduce(t, op):
+        if args.backend == "nccl":
+            dist.all_reduce(t, op=op)
+            return t
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        return h
 
     sd = make_scene(pkg, args)
     W, H = args.width, args.height
@@ -122,7 +146,7 @@ def main():
     for k in range(args.warmup):
         step(k, max(1, args.warmup * spp_step), 1 if k else 0)
     if distributed and args.warmup:
-        dist.reduce(fb, dst=0)
+        reduce_to_rank0(fb)
     fb.zero_()
 
     barrier()
@@ -133,16 +157,14 @@ def main():
         d = st.as_dict()
         agg = d if agg is None else {key: agg[key] + d[key] for key in d}
     if distributed:
-        dist.reduce(fb, dst=0)  # RCCL framebuffer merge over xGMI, inside the timed region
+        reduce_to_rank0(fb)  # RCCL framebuffer merge over xGMI, inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmax = allreduce(torch.tensor([dt], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        cnt = torch.tensor([agg["samples"], agg["vertices"], agg["ref_scene_rays"], agg["closest_rays"], agg["shadow_rays"]],
-                           dtype=torch.float64, device=dev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        cnt = allreduce(torch.tensor([agg["samples"], agg["vertices"], agg["ref_scene_rays"], agg["closest_rays"], agg["shadow_rays"]],
+                                     dtype=torch.float64, device=dev), dist.ReduceOp.SUM)
         tot_samples, tot_vertices, tot_ref_rays, tot_closest, tot_shadow = [float(x) for x in cnt.tolist()]
     else:
         tot_samples, tot_vertices, tot_ref_rays = float(agg["samples"]), float(agg["vertices"]), float(agg["ref_scene_rays"])

@@ -144,6 +144,19 @@ def test_tile_partition_is_bit_identical(pkg, hip):
     assert not ((parts[0] != 0) & (parts[1] != 0)).any()
 
 
+def test_two_pools_match_one_pool(pkg, hip, monkeypatch):
+    """The two-pool schedule (two host threads, disjoint halves of each pass) changes nothing in the frame."""
+    sd = pkg.scenes.cornell_demo(96, 96, 8)
+    monkeypatch.setenv("MCPT_POOLS", "1")
+    one, st1 = hip.HipScene(sd).render(spp=8, seed=4, spp_per_pass=4)
+    monkeypatch.setenv("MCPT_POOLS", "2")
+    monkeypatch.setenv("MCPT_POOL_MIN_WORK", "1000")
+    hs = hip.HipScene(sd)
+    two, st2 = hs.render(spp=8, seed=4, spp_per_pass=4, pool_paths=3 * 8192)
+    assert np.array_equal(one, two, equal_nan=True)
+    assert st2.vertices == st1.vertices and st2.shaded == st1.shaded and st2.shadow_rays == st1.shadow_rays
+
+
 def test_progressive_accumulation_matches_single_call(pkg, hip):
     sd = pkg.scenes.cornell_rc(64, 64, 8)
     hs = hip.HipScene(sd)
