@@ -48,5 +48,11 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_host(verbose=False):
+    """The C++ host mirror of the reference's executable (host/RayTracing, host/RayTracingDemo)."""
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "host")], stdout=None if verbose else subprocess.DEVNULL)
+    return os.path.join(HERE, "host", "RayTracing")
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
