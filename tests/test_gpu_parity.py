@@ -133,6 +133,48 @@ def test_render_psnr_chess(pkg, oracle, hip):
     assert abs(st_gpu.ref_scene_rays - st_ref.scene_rays) <= 0.002 * st_ref.scene_rays
 
 
+def _with_env(sd, seed=0):
+    """A synthetic 64x32 lat-long environment map (the reference's sky.png is missing from its snapshot)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:32, 0:64]
+    env = np.stack([0.2 + 0.6 * (yy / 31.0), 0.3 + 0.5 * np.sin(xx / 64.0 * 2 * np.pi) ** 2, 0.9 - 0.5 * (yy / 31.0)], axis=2)
+    sd.env_pixels = (env + 0.05 * rng.random(env.shape)).astype(np.float32)
+    return sd
+
+
+def test_render_psnr_with_environment_map(pkg, oracle, hip):
+    """Scene::sampleEnv (Scene.hpp:60-99): lat-long lookup with bilinear filtering, on misses and as the l_ind factor."""
+    sd = _with_env(pkg.scenes.chess_scene(width=200, height=112, spp=8))
+    psnr, st_ref, st_gpu, fb_ref, fb_gpu = _psnr_case(pkg, oracle, hip, sd, 8)
+    assert psnr >= 40.0, "PSNR %.2f dB" % psnr
+    sky = fb_ref[:20].reshape(-1, 3)
+    assert sky.std(axis=0).max() > 0.01  # the map is actually visible in the sky rows
+    # cast_rays with the map: per-path agreement
+    os_, hs = oracle.OracleScene(sd), hip.HipScene(sd)
+    rng = np.random.default_rng(2)
+    n = 20000
+    pix = rng.integers(0, 200 * 112, size=n).astype(np.uint32)
+    smp = rng.integers(0, 64, size=n).astype(np.uint32)
+    ch = rng.integers(0, 3, size=n).astype(np.int32)
+    o, d = os_.camera_rays(pix, smp, seed=3)
+    ref, gpu = os_.cast_rays(o, d, pix, smp, ch, seed=3), hs.cast_rays(o, d, pix, smp, ch, seed=3)
+    assert (np.abs(ref - gpu) <= 1e-4 * np.maximum(1.0, np.abs(ref))).mean() >= 0.99
+
+
+def test_render_without_shadows_and_with_more_light_samples(pkg, oracle, hip):
+    """includeShadow=false (Scene.cpp:74) and n_dir_sample != 4 (Scene::setDirectLightSample, Scene.hpp:114)."""
+    sd = pkg.scenes.cornell_rc(64, 64, 8)
+    sd.enable_shadow = False
+    psnr, *_ = _psnr_case(pkg, oracle, hip, sd, 8)
+    assert psnr >= 40.0, "no-shadow PSNR %.2f dB" % psnr
+    sd = pkg.scenes.cornell_demo(64, 64, 4)
+    os_, hs = oracle.OracleScene(sd), hip.HipScene(sd)
+    fb_ref, _ = os_.render(spp=4, seed=1, n_dir_sample=9)
+    fb_gpu, st = hs.render(spp=4, seed=1, n_dir_sample=9)
+    assert pkg.pngio.psnr_u8(pkg.pngio.tonemap_u8(fb_ref), pkg.pngio.tonemap_u8(fb_gpu)) >= 40.0
+    assert st.direct_vertices <= st.shaded and st.shadow_rays <= 9 * st.direct_vertices
+
+
 def test_tile_partition_is_bit_identical(pkg, hip):
     """a tile-partitioned frame (2 ranks, summed) equals the 1-rank frame bit for bit."""
     sd = pkg.scenes.cornell_rc(96, 64, 4)
