@@ -318,9 +318,8 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     while (n_cur_max > 0) {
         const int nxt = cur ^ 1;
         Wave cw = w.wave[cur].view(), nx = w.wave[nxt].view();
-        HIP_TRY(hipMemsetAsync(&w.counters.p->n_paths[nxt], 0, sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(&w.counters.p->n_rays[nxt], 0, sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(&w.counters.p->n_direct, 0, sizeof(uint32_t), st));
+        // (the counters of list `nxt` and the work-list lengths were cleared by launch_reset_counters of the
+        // previous iteration, or by k_init_free)
         int ev = T.begin(st);
         launch_shade(sc->view, C, cw, nx, w.scratch(), cur, n_cur_max, st);
         T.end(ev, K_SHADE, st);
@@ -351,7 +350,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             next_work += g;
             tot.closest += g;
         }
-        HIP_TRY(hipMemsetAsync(&w.counters.p->n_shadow, 0, sizeof(uint32_t), st));
+        launch_reset_counters(w.counters.p, cur, st);  // list `cur` is consumed: it is the next iteration's output
         if (n_direct > 0) {
             ev = T.begin(st);
             launch_direct(sc->view, C, nx, w.scratch(), n_direct, st);

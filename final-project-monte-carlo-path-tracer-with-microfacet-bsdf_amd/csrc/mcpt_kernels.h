@@ -74,6 +74,9 @@ struct CameraConst {
 };
 
 void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, hipStream_t s);
+// After k_shade(cur -> next) has completed and its counters were copied to the host: clears the counters of list
+// `cur` (the next iteration's output list) and the per-iteration work-list lengths, in one launch.
+void launch_reset_counters(Counters *c, int cur_idx, hipStream_t s);
 // Camera ray + closest hit for `n_samples` new samples, fused: a miss or a depth-0 emitter hit writes the
 // three channel results directly; any other hit appends one ray/hit entry and three fresh path records to
 // wave `next` (list index `next_idx`).

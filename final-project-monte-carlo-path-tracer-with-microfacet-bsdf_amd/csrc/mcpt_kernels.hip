@@ -807,6 +807,19 @@ inline uint32_t blocks(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 }  // namespace
 
+__global__ void k_reset_counters(Counters *c, int cur_idx) {
+    if (threadIdx.x == 0) {
+        c->n_paths[cur_idx].v = 0;
+        c->n_rays[cur_idx].v = 0;
+        c->n_direct.v = 0;
+        c->n_shadow.v = 0;
+    }
+}
+
+void launch_reset_counters(Counters *c, int cur_idx, hipStream_t s) {
+    hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(64), 0, s, c, cur_idx);
+}
+
 void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, hipStream_t s) {
     hipLaunchKernelGGL(k_init_free, dim3(blocks(pool)), dim3(kBlock), 0, s, free_slots, c, pool);
 }
