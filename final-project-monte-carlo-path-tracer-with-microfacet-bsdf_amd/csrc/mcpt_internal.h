@@ -33,7 +33,8 @@ struct alignas(16) TriGeom {
     float e1yz[2];
     float e2xy[2];
     float e2z;
-    int32_t pad[3];
+    uint32_t mat_bits;  // material index | emissive << 31 (carried into the hit record: saves k_shade two dependent loads)
+    int32_t pad[2];
 };
 static_assert(sizeof(TriGeom) == 48, "TriGeom must be 48 bytes");
 
@@ -52,7 +53,8 @@ struct alignas(16) SphereRec {  // Sphere.hpp:14-18
     float radius;
     float radius2;
     int32_t mat;
-    int32_t pad[2];
+    uint32_t mat_bits;  // material index | emissive << 31
+    int32_t pad;
 };
 static_assert(sizeof(SphereRec) == 32, "SphereRec must be 32 bytes");
 

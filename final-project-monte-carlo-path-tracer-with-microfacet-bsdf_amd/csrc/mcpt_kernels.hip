@@ -25,6 +25,10 @@ namespace mcpt {
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef MCPT_SHADE_BLOCK
+#define MCPT_SHADE_BLOCK 512
+#endif
+constexpr int kShadeBlock = MCPT_SHADE_BLOCK;  // k_shade: larger workgroups = fewer allocation atomics per hot counter
 
 MCPT_DI uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -33,14 +37,16 @@ MCPT_DI uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amd
 // wave and counter: the hot counters are the only cross-workgroup contention points of the pipeline.
 // Must be called by every thread of the block (it contains barriers).
 constexpr int kMaxAlloc = 6;
+constexpr int kMaxWaves = 16;
 struct BlockAllocShared {
-    uint32_t cnt[kBlock / 64][kMaxAlloc];
+    uint32_t cnt[kMaxWaves][kMaxAlloc];
     uint32_t base[kMaxAlloc];
 };
 
 template <int N>
 MCPT_DI void block_alloc(BlockAllocShared &sh, const bool (&want)[N], const uint32_t (&mult)[N], uint32_t *const (&counter)[N],
                          const bool (&subtract)[N], uint32_t (&index)[N]) {
+    const uint32_t n_waves = blockDim.x >> 6;
     static_assert(N <= kMaxAlloc, "too many allocation requests");
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
@@ -56,8 +62,7 @@ MCPT_DI void block_alloc(BlockAllocShared &sh, const bool (&want)[N], const uint
     for (int k = 0; k < N; ++k) {
         if (threadIdx.x == (unsigned)k) {  // lanes 0..N-1 of wave 0 issue their atomics in the same instruction
             uint32_t total = 0;
-#pragma unroll
-            for (int w = 0; w < kBlock / 64; ++w) total += sh.cnt[w][k];
+            for (uint32_t w = 0; w < n_waves; ++w) total += sh.cnt[w][k];
             uint32_t base = 0;
             if (total) {
                 const uint32_t amount = total * mult[k];
@@ -90,7 +95,8 @@ MCPT_DI f3 ld3(float4 v) { return mk3(v.x, v.y, v.z); }
 struct TraceResult {
     double t;
     int32_t prim;
-    bool visible;  // shadow queries only
+    uint32_t mat_bits;  // closest hit: material index | emissive << 31
+    bool visible;       // shadow queries only
 };
 
 // One traversal loop, three query kinds:
@@ -105,6 +111,7 @@ enum { kClosest = 0, kWindow = 1, kOccluder = 2 };
 struct TraceState {
     double best_t;
     int32_t best_prim;
+    uint32_t best_mat;
     bool occluded, found;
 #ifdef MCPT_TRAVERSAL_STATS
     unsigned nv, nt, iters;
@@ -163,11 +170,16 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
             const int32_t prim = ~cur;
             double t = 0, u, v;
             bool h;
+            uint32_t mb;
             if (prim < S.n_tri) {
-                h = tri_hit(S.tri_geom[prim], r, t, u, v);
+                const TriGeom g = S.tri_geom[prim];
+                mb = g.mat_bits;
+                h = tri_hit(g, r, t, u, v);
             } else {
                 float ts = 0.f;
-                h = sphere_hit(S.spheres[prim - S.n_tri], r, ts);
+                const SphereRec sp = S.spheres[prim - S.n_tri];
+                mb = sp.mat_bits;
+                h = sphere_hit(sp, r, ts);
                 t = (double)ts;
             }
             if (h) {
@@ -181,6 +193,7 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
                 } else if (t < st.best_t || (t == st.best_t && prim > st.best_prim)) {
                     st.best_t = t;
                     st.best_prim = prim;
+                    st.best_mat = mb;
                     lim = (float)(t + (fabs(t) * 1e-4 + 1e-2));
                 }
             }
@@ -195,6 +208,7 @@ MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_
     TraceState st;
     st.best_t = DBL_MAX;
     st.best_prim = -1;
+    st.best_mat = 0;
     st.occluded = false;
     st.found = false;
 #ifdef MCPT_TRAVERSAL_STATS
@@ -231,12 +245,12 @@ MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_
         atomicAdd(&S.dbg[base + 5], (unsigned long long)(SHADOW ? (st.found ? 1 : 0) : 0));
     }
 #endif
-    return TraceResult{st.best_t, st.best_prim, !st.occluded && st.found};
+    return TraceResult{st.best_t, st.best_prim, st.best_mat, !st.occluded && st.found};
 }
 
-MCPT_DI uint4 pack_hit(double t, int32_t prim) {
+MCPT_DI uint4 pack_hit(double t, int32_t prim, uint32_t mat_bits) {  // {t lo, t hi, prim, material | emissive << 31}
     const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
-    return make_uint4((uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)prim, 0u);
+    return make_uint4((uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)prim, mat_bits);
 }
 
 template <int STK>
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n
     if (i >= n) return;
     const Ray r = make_ray(ld3(ray_o[i]), ld3(ray_d[i]));
     const TraceResult tr = traverse<false, STK>(S, r, 0.f, stk, tid);
-    hit[i] = pack_hit(tr.t, tr.prim);
+    hit[i] = pack_hit(tr.t, tr.prim, tr.mat_bits);
 }
 
 // Shadow queue consumer: a fixed grid strides over the queue, whose length is only known on the device.
@@ -332,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
     const uint32_t s = first_sample + j;
     bool surface = false;
     f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1);
-    TraceResult tr{DBL_MAX, -1, false};
+    TraceResult tr{DBL_MAX, -1, 0u, false};
     if (valid) {
         const uint32_t pl = s / (uint32_t)C.s_pass;
         const uint32_t m = C.pixel_list ? C.pixel_list[pl] : pl;
@@ -346,20 +360,18 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
             C.result[(size_t)s * 3 + 1] = env.y;
             C.result[(size_t)s * 3 + 2] = env.z;
         } else {
-            int mat;
-            f3 n;
-            if (tr.prim < S.n_tri) {
-                const TriShade ts = S.tri_shade[tr.prim];
-                mat = ts.mat;
-                n = mk3(ts.n[0], ts.n[1], ts.n[2]);
-            } else {
-                const SphereRec sp = S.spheres[tr.prim - S.n_tri];
-                mat = sp.mat;
-                const f3 p = pos + dir * (float)tr.t;
-                n = normalized(p - mk3(sp.c[0], sp.c[1], sp.c[2]));
-            }
-            const MaterialRec &M = S.mats[mat];
-            if (M.hasEmission) {
+            const int mat = (int)(tr.mat_bits & 0x7fffffffu);
+            if (tr.mat_bits >> 31) {  // depth-0 emitter, Scene.cpp:102-107
+                const MaterialRec &M = S.mats[mat];
+                f3 n;
+                if (tr.prim < S.n_tri) {
+                    const TriShade ts = S.tri_shade[tr.prim];
+                    n = mk3(ts.n[0], ts.n[1], ts.n[2]);
+                } else {
+                    const SphereRec sp = S.spheres[tr.prim - S.n_tri];
+                    const f3 p = pos + dir * (float)tr.t;
+                    n = normalized(p - mk3(sp.c[0], sp.c[1], sp.c[2]));
+                }
                 const float c = fabsf(dot(-dir, n));
                 C.result[(size_t)s * 3 + 0] = clampf(0, 1, M.emit[0] * c);
                 C.result[(size_t)s * 3 + 1] = clampf(0, 1, M.emit[1] * c);
@@ -379,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
     const uint32_t ri = idx[0], pi = idx[1], fi = idx[2];
     next.ray_o[ri] = make_float4(pos.x, pos.y, pos.z, 0.f);
     next.ray_d[ri] = make_float4(dir.x, dir.y, dir.z, 0.f);
-    next.hit[ri] = pack_hit(tr.t, tr.prim);
+    next.hit[ri] = pack_hit(tr.t, tr.prim, tr.mat_bits);
 #pragma unroll
     for (uint32_t c = 0; c < 3; ++c) {
         const uint32_t slot = C.free_slots[fi + c];
@@ -542,9 +554,9 @@ MCPT_DI float unwind(const RenderConst &C, uint32_t slot, uint32_t depth, float 
     return X;
 }
 
-__global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wave cur, Wave next, Scratch Xs, int cur_idx) {
+__global__ __launch_bounds__(kShadeBlock) void k_shade(DevScene S, RenderConst C, Wave cur, Wave next, Scratch Xs, int cur_idx) {
     __shared__ BlockAllocShared sh;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
     const uint32_t n_cur = C.counters->n_paths[cur_idx].v;  // the grid is an upper bound; the list length lives on the device
     const bool valid = i < n_cur;
     const int next_idx = cur_idx ^ 1;
@@ -556,6 +568,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wav
     float X = 0.f;
     double hit_t = 0;
     int32_t hit_prim = -1;
+    uint32_t hit_mat = 0;
 
     if (valid) {
         const uint4 r0 = cur.rec0[i];
@@ -581,11 +594,8 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wav
                 const uint4 h = cur.hit[ray_idx];
                 hit_t = __longlong_as_double((long long)(((unsigned long long)h.y << 32) | h.x));
                 hit_prim = (int32_t)h.z;
-                bool surface = false;
-                if (hit_prim >= 0) {
-                    const int mat = hit_prim < S.n_tri ? S.tri_shade[hit_prim].mat : S.spheres[hit_prim - S.n_tri].mat;
-                    surface = !S.mats[mat].hasEmission;  // Scene.cpp:135,162
-                }
+                hit_mat = h.w;
+                const bool surface = hit_prim >= 0 && !(hit_mat >> 31);  // Scene.cpp:135,162
                 if (!surface) {
                     const f3 wi = ld3(cur.ray_d[ray_idx]);
                     const float env = comp(sample_env(S, wi), ch);  // Scene.cpp:145-149,172-176
@@ -607,6 +617,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wav
             const uint4 h = cur.hit[ray_idx];
             hit_t = __longlong_as_double((long long)(((unsigned long long)h.y << 32) | h.x));
             hit_prim = (int32_t)h.z;
+            hit_mat = h.w;
             if (hit_prim < 0) {
                 X = comp(sample_env(S, ld3(cur.ray_d[ray_idx])), ch);  // Scene.cpp:88-95
                 finished = true;
@@ -619,13 +630,12 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wav
     // ---- vertex set-up for lanes that shade
     f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), p = mk3(0, 0, 0), n = mk3(0, 0, 1), wo = mk3(0, 0, -1);
     f2 uv{0.f, 0.f};
-    int mat_id = 0;
+    const int mat_id = (int)(hit_mat & 0x7fffffffu);
     if (do_shade) {
         ro = ld3(cur.ray_o[ray_idx]);
         rd = ld3(cur.ray_d[ray_idx]);
         if (hit_prim < S.n_tri) {
             const TriShade ts = S.tri_shade[hit_prim];
-            mat_id = ts.mat;
             n = mk3(ts.n[0], ts.n[1], ts.n[2]);
             p = ro + rd * (float)hit_t;  // Triangle.hpp:245 / Ray.hpp:21
             if (S.mats[mat_id].textured) {  // Triangle.hpp:248: recompute the barycentrics of the recorded hit
@@ -639,12 +649,11 @@ __global__ __launch_bounds__(kBlock) void k_shade(DevScene S, RenderConst C, Wav
             }
         } else {
             const SphereRec s = S.spheres[hit_prim - S.n_tri];
-            mat_id = s.mat;
             p = ro + rd * (float)hit_t;  // Sphere.hpp:40 (t0 is a float)
             n = normalized(p - mk3(s.c[0], s.c[1], s.c[2]));
         }
         wo = -rd;
-        if (depth == 0 && S.mats[mat_id].hasEmission) {  // Scene.cpp:102-107
+        if (depth == 0 && (hit_mat >> 31)) {  // Scene.cpp:102-107
             X = clampf(0, 1, S.mats[mat_id].emit[ch] * fabsf(dot(wo, n)));
             finished = true;
             do_shade = false;
@@ -878,7 +887,7 @@ void launch_trace_shadow(const DevScene &S, const Counters *counters, uint32_t n
 void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, Scratch X, int cur_idx, uint32_t n_cur_max,
                   hipStream_t s) {
     if (n_cur_max == 0) return;
-    hipLaunchKernelGGL(k_shade, dim3(blocks(n_cur_max)), dim3(kBlock), 0, s, S, C, cur, next, X, cur_idx);
+    hipLaunchKernelGGL(k_shade, dim3((n_cur_max + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, s, S, C, cur, next, X, cur_idx);
 }
 
 void launch_accumulate(const float *result, const uint32_t *pixel_list, uint32_t n_pix, int32_t s_pass, float spp_total,

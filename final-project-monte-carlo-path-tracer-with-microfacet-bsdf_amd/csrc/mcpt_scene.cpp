@@ -313,6 +313,7 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) 
             s.radius = o.radius;
             s.radius2 = o.radius * o.radius;
             s.mat = o.material;
+            s.mat_bits = (uint32_t)o.material | (hs.materials[o.material].hasEmission ? 0x80000000u : 0u);
             B.prim = d.n_triangles + oi;
             const V3 c = ld(o.center);
             B.bounds = box_pp({c.x - o.radius, c.y - o.radius, c.z - o.radius}, {c.x + o.radius, c.y + o.radius, c.z + o.radius});
@@ -351,6 +352,7 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) 
                 g.e2xy[0] = e2.x;
                 g.e2xy[1] = e2.y;
                 g.e2z = e2.z;
+                g.mat_bits = (uint32_t)o.material | (hs.materials[o.material].hasEmission ? 0x80000000u : 0u);
                 TriShade &s = hs.tri_shade[ti];
                 std::memset(&s, 0, sizeof s);
                 store3(s.n, n);

@@ -7,11 +7,11 @@ import sys
 
 
 def short(name):
-    if "k_trace<true" in name:
+    if "k_trace<true" in name or "k_trace_shadow" in name:
         return "k_trace<shadow>"
-    if "k_trace<false" in name:
+    if "k_trace<false" in name or "k_trace_closest" in name:
         return "k_trace<closest>"
-    for k in ("k_shade", "k_primary", "k_accumulate", "k_init_free", "k_generate_explicit"):
+    for k in ("k_shade", "k_direct", "k_primary", "k_accumulate", "k_init_free", "k_generate_explicit"):
         if k in name:
             return k
     return None
