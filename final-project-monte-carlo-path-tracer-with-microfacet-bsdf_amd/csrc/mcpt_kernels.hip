@@ -43,14 +43,16 @@ struct BlockAllocShared {
     uint32_t base[kMaxAlloc];
 };
 
+// begin: ballots, per-wave counts to LDS, one barrier, then lanes 0..N-1 of wave 0 issue the atomics and publish the
+// bases.  end: second barrier, per-lane indices.  Work that does not need the indices can sit between the two calls:
+// the other waves then compute while wave 0 waits for its atomics to return.
 template <int N>
-MCPT_DI void block_alloc(BlockAllocShared &sh, const bool (&want)[N], const uint32_t (&mult)[N], uint32_t *const (&counter)[N],
-                         const bool (&subtract)[N], uint32_t (&index)[N]) {
-    const uint32_t n_waves = blockDim.x >> 6;
+MCPT_DI void block_alloc_begin(BlockAllocShared &sh, const bool (&want)[N], const uint32_t (&mult)[N], uint32_t *const (&counter)[N],
+                               const bool (&subtract)[N], uint32_t (&prefix)[N]) {
     static_assert(N <= kMaxAlloc, "too many allocation requests");
+    const uint32_t n_waves = blockDim.x >> 6;
     const uint32_t lane = lane_id();
     const uint32_t wave = threadIdx.x >> 6;
-    uint32_t prefix[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const unsigned long long mask = __ballot(want[k]);
@@ -71,6 +73,11 @@ MCPT_DI void block_alloc(BlockAllocShared &sh, const bool (&want)[N], const uint
             sh.base[k] = base;
         }
     }
+}
+
+template <int N>
+MCPT_DI void block_alloc_end(BlockAllocShared &sh, const uint32_t (&mult)[N], const uint32_t (&prefix)[N], uint32_t (&index)[N]) {
+    const uint32_t wave = threadIdx.x >> 6;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < N; ++k) {
@@ -78,6 +85,14 @@ MCPT_DI void block_alloc(BlockAllocShared &sh, const bool (&want)[N], const uint
         for (uint32_t w = 0; w < wave; ++w) before += sh.cnt[w][k];
         index[k] = sh.base[k] + (before + prefix[k]) * mult[k];
     }
+}
+
+template <int N>
+MCPT_DI void block_alloc(BlockAllocShared &sh, const bool (&want)[N], const uint32_t (&mult)[N], uint32_t *const (&counter)[N],
+                         const bool (&subtract)[N], uint32_t (&index)[N]) {
+    uint32_t prefix[N];
+    block_alloc_begin<N>(sh, want, mult, counter, subtract, prefix);
+    block_alloc_end<N>(sh, mult, prefix, index);
 }
 
 MCPT_DI f3 ld3(float4 v) { return mk3(v.x, v.y, v.z); }
@@ -554,7 +569,7 @@ MCPT_DI float unwind(const RenderConst &C, uint32_t slot, uint32_t depth, float 
     return X;
 }
 
-__global__ __launch_bounds__(kShadeBlock) void k_shade(DevScene S, RenderConst C, Wave cur, Wave next, Scratch Xs, int cur_idx) {
+__global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderConst C, Wave cur, Wave next, Scratch Xs, int cur_idx) {
     __shared__ BlockAllocShared sh;
     const uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
     const uint32_t n_cur = C.counters->n_paths[cur_idx].v;  // the grid is an upper bound; the list length lives on the device
@@ -682,25 +697,41 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DevScene S, RenderConst C
 #endif
 
     // one round of block-aggregated atomics: released slots, next-list records, continuation rays, the direct-
-    // lighting work list, statistics
-    uint32_t j, rj, dj;
-    {
-        const bool want[6] = {finished, do_shade, has_cont, need_direct, pushed, overflow};
-        const uint32_t mult[6] = {1u, 1u, 1u, 1u, 1u, 1u};
-        uint32_t *const ctr[6] = {&C.counters->n_free.v, &C.counters->n_paths[next_idx].v, &C.counters->n_rays[next_idx].v,
-                                  &C.counters->n_direct.v, &C.counters->pushes.v, &C.counters->overflow.v};
-        const bool sub[6] = {false, false, false, false, false, false};
-        uint32_t idx[6];
-        block_alloc<6>(sh, want, mult, ctr, sub, idx);
-        if (finished) C.free_slots[idx[0]] = slot;
-        j = idx[1];
-        rj = idx[2];
-        dj = idx[3];
-    }
-    if (!do_shade) return;
+    // lighting work list, statistics.  The BSDF sampling below does not need the indices and runs while the
+    // atomics are in flight.
+    const bool want[6] = {finished, do_shade, has_cont, need_direct, pushed, overflow};
+    const uint32_t mult[6] = {1u, 1u, 1u, 1u, 1u, 1u};
+    uint32_t *const ctr[6] = {&C.counters->n_free.v, &C.counters->n_paths[next_idx].v, &C.counters->n_rays[next_idx].v,
+                              &C.counters->n_direct.v, &C.counters->pushes.v, &C.counters->overflow.v};
+    const bool sub[6] = {false, false, false, false, false, false};
+    uint32_t prefix[6], idx[6];
+    block_alloc_begin<6>(sh, want, mult, ctr, sub, prefix);
 
-    const f3 mfn = mat_sample(m, n, u0[0], u0[1]);   // Scene.cpp:109
-    const float kr = mat_fresnel(m, rd, mfn, ch);    // Scene.cpp:110
+    float kr = 0.f, ev = 0.f, aw = 0.f, pd = 0.f;
+    f3 p2 = mk3(0, 0, 0), wi = mk3(0, 0, 1);
+    if (do_shade) {
+        const f3 mfn = mat_sample(m, n, u0[0], u0[1]);   // Scene.cpp:109
+        kr = mat_fresnel(m, rd, mfn, ch);                // Scene.cpp:110
+        const bool isReflect = u0[3] < kr;               // Scene.cpp:123
+        if (isReflect) p2 = (dot(wo, mfn) < 0) ? (p - n * kEps) : (p + n * kEps);  // Scene.cpp:124-128
+        else p2 = (dot(wo, mfn) < 0) ? (p + n * kEps) : (p - n * kEps);            // Scene.cpp:151-155
+        if (has_cont) {
+            wi = isReflect ? mat_reflect(wo, mfn) : mat_refract(m, rd, mfn, ch);   // Scene.cpp:132,159
+            ev = mat_eval(m, wi, wo, n, ch, uv, isReflect);
+            if (m.isDirac) {
+                aw = -1.f;
+            } else {
+                aw = fabsf(dot(wo, n));
+                pd = mat_pdf(m, wi, wo, n, ch, isReflect);
+            }
+        }
+    }
+
+    block_alloc_end<6>(sh, mult, prefix, idx);
+    if (finished) C.free_slots[idx[0]] = slot;
+    if (!do_shade) return;
+    const uint32_t j = idx[1], rj = idx[2], dj = idx[3];
+
     if (need_direct) {  // work-list entry for k_direct (Scene::directLighting runs there, one lane per light sample)
         Xs.vtx0[dj] = make_float4(q.x, q.y, q.z, uv.x);
         Xs.vtx1[dj] = make_float4(n.x, n.y, n.z, uv.y);
@@ -708,25 +739,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(DevScene S, RenderConst C
                                                                     (zero_direct ? (1u << 19) : 0u)));
         Xs.vtx_j[dj] = j;
     }
-
-    const bool isReflect = u0[3] < kr;  // Scene.cpp:123
-    f3 p2;
-    if (isReflect) p2 = (dot(wo, mfn) < 0) ? (p - n * kEps) : (p + n * kEps);  // Scene.cpp:124-128
-    else p2 = (dot(wo, mfn) < 0) ? (p + n * kEps) : (p - n * kEps);            // Scene.cpp:151-155
-
     uint32_t flags = depth | (inside ? kInside : 0u) | (need_direct ? 0u : kNoDirect);
-    float ev = 0.f, aw = 0.f, pd = 0.f;
     if (has_cont) {
-        const f3 wi = isReflect ? mat_reflect(wo, mfn) : mat_refract(m, rd, mfn, ch);  // Scene.cpp:132,159
         next.ray_o[rj] = make_float4(p2.x, p2.y, p2.z, 0.f);
         next.ray_d[rj] = make_float4(wi.x, wi.y, wi.z, 0.f);
-        ev = mat_eval(m, wi, wo, n, ch, uv, isReflect);
-        if (m.isDirac) {
-            aw = -1.f;
-        } else {
-            aw = fabsf(dot(wo, n));
-            pd = mat_pdf(m, wi, wo, n, ch, isReflect);
-        }
     } else {
         flags |= kTerminate;
     }

@@ -27,6 +27,8 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def hip(pkg):
-    """The HIP backend; building is the job of __graft_entry__.build(), loading must not fall back to anything."""
+    """The HIP backend.  Built in-tree with hipcc when missing or stale (hipcc cross-compiles gfx950 without a GPU);
+    loading must not fall back to anything."""
+    pkg.build.build()
     pkg.hip_backend.lib()
     return pkg.hip_backend
