@@ -101,6 +101,8 @@ struct SharedBufs {
     DevBuf<float> result;
     DevBuf<uint32_t> pixel_list, key_pixel, key_sample;
     DevBuf<int32_t> key_channel;
+    int pix_key[5] = {0, 0, 0, 0, 0};  // (W, H, tile, rank, nranks) of the pixel list currently in HBM
+    uint32_t n_pix = 0;
     void release() {
         result.release(); pixel_list.release(); key_pixel.release(); key_sample.release(); key_channel.release();
     }
@@ -388,9 +390,18 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     const auto t0 = std::chrono::steady_clock::now();
     const int W = cam->width, H = cam->height;
 
-    std::vector<uint32_t> pix;
-    build_pixel_list(W, H, p.tile_size, p.nranks > 1 ? p.rank : 0, p.nranks > 1 ? p.nranks : 1, pix);
-    const uint32_t n_pix = (uint32_t)pix.size();
+    // owned pixels: rebuilt and uploaded only when the partition changes (progressive calls reuse it)
+    SharedBufs &sh = sc->shared;
+    const int pk[5] = {W, H, p.tile_size, p.nranks > 1 ? p.rank : 0, p.nranks > 1 ? p.nranks : 1};
+    if (std::memcmp(pk, sh.pix_key, sizeof pk) != 0 || !sh.pixel_list.p) {
+        std::vector<uint32_t> pix;
+        build_pixel_list(W, H, pk[2], pk[3], pk[4], pix);
+        sh.n_pix = (uint32_t)pix.size();
+        HIP_TRY(sh.pixel_list.alloc(std::max<size_t>(pix.size(), 1)));
+        if (!pix.empty()) HIP_TRY(hipMemcpy(sh.pixel_list.p, pix.data(), pix.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        std::memcpy(sh.pix_key, pk, sizeof pk);
+    }
+    const uint32_t n_pix = sh.n_pix;
 
     int s_pass = p.spp_per_pass > 0 ? p.spp_per_pass : 32;
     s_pass = std::min(s_pass, p.spp);
@@ -414,11 +425,8 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
         if (stats) std::memset(stats, 0, sizeof *stats);
         return MCPT_OK;
     }
-    SharedBufs &sh = sc->shared;
     for (int k = 0; k < n_pools; ++k) HIP_TRY(ensure_workspace(sc->pools[k], pool, p.n_dir_sample, max_depth));
     HIP_TRY(sh.result.alloc((size_t)n_pix * s_pass * 3));
-    HIP_TRY(sh.pixel_list.alloc(n_pix));
-    HIP_TRY(hipMemcpyAsync(sh.pixel_list.p, pix.data(), (size_t)n_pix * sizeof(uint32_t), hipMemcpyHostToDevice, st));
 
     RenderConst C;
     std::memset(&C, 0, sizeof C);

@@ -1,0 +1,20 @@
+import sys, time
+sys.path.insert(0, '.')
+import torch, mcpt_loader
+pkg = mcpt_loader.load()
+sd = pkg.scenes.chess_scene(width=1920, height=1080, spp=256)
+hs = pkg.HipScene(sd, device=0)
+fb = torch.zeros(1920*1080*3, dtype=torch.float32, device='cuda')
+st = torch.cuda.current_stream()
+def run(nranks, steps=4):
+    hs.render_device(fb.data_ptr(), st.cuda_stream, spp=256, spp_total=1024, accumulate=0, rank=0, nranks=nranks, spp_per_pass=256)
+    torch.cuda.synchronize(); t=time.perf_counter(); its=0
+    for k in range(steps):
+        s = hs.render_device(fb.data_ptr(), st.cuda_stream, spp=256, spp_total=1024, sample_offset=k*256, accumulate=1, rank=0, nranks=nranks, spp_per_pass=256)
+        its += s.iterations
+    torch.cuda.synchronize(); dt=(time.perf_counter()-t)/steps
+    return dt*1e3, its/steps
+base,_ = run(1)
+for n in (1,2,4,8):
+    ms, its = run(n)
+    print("nranks=%d: %.1f ms/step (ideal %.1f), efficiency %.2f, iterations/step %.0f" % (n, ms, base/n, base/n/ms, its))
