@@ -722,6 +722,9 @@ static float scene_direct_lighting(const render_ctx *rc, v3 wo, const intersecti
     float l_dir = 0;
     float pdf = 0;
     intersection inter = no_hit();
+    /* Without an emitter Scene::sampleLight (Scene.cpp:23-37) returns without touching `pdf`, which the reference then
+     * reads uninitialised (undefined behaviour).  Convention here and in the GPU path: no emitter, no direct light. */
+    if (rc->s->n_lights == 0) return 0;
     for (int i = 0; i < rc->n_dir_sample; i++) {
         float u[4];
         rng_block(rk, depth, 1u + (uint32_t)i, u);
