@@ -311,17 +311,50 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             next_work = n_work;
             n_cur_max = n_work;
             int ev = T.begin(st);
-            launch_trace_closest(sc->view, n_work, nx.ray_o, nx.ray_d, nx.hit, st);
+            launch_trace_closest(sc->view, n_work, nullptr, nx.ray_o, nx.ray_d, nx.hit, st);
             T.end(ev, K_CLOSEST, st);
             tot.closest += n_work;
         }
     }
 
+    const char *db = std::getenv("MCPT_DRAIN_BATCH");  // iterations queued per host sync once no samples are left to issue
+    const int drain_batch = db ? std::max(1, std::atoi(db)) : 4;
     while (n_cur_max > 0) {
+        // (big lists keep the three-stream schedule with exact launch sizes: over-sized grids only pay off when small)
+        const bool draining = ((C.mode != 0) || next_work >= n_work) && n_cur_max <= (2u << 20);
+        if (draining && drain_batch > 1) {
+            // Drain phase: no regeneration, so list lengths only shrink.  Several iterations are queued back to back
+            // on one stream with the last known length as the grid bound (every kernel reads the true lengths on the
+            // device); the host looks at the counters once per batch.
+            for (int it = 0; it < drain_batch; ++it) {
+                const int nxt = cur ^ 1;
+                Wave cw = w.wave[cur].view(), nx = w.wave[nxt].view();
+                int ev = T.begin(st);
+                launch_shade(sc->view, C, cw, nx, w.scratch(), cur, n_cur_max, st);
+                T.end(ev, K_SHADE, st);
+                launch_bookkeep(w.counters.p, cur, false, 0, 0, 0, st);
+                ev = T.begin(st);
+                launch_direct(sc->view, C, nx, w.scratch(), nxt, n_cur_max, st);
+                T.end(ev, K_DIRECT, st);
+                if (C.enable_shadow) {
+                    ev = T.begin(st);
+                    launch_trace_shadow(sc->view, w.counters.p, nxt, n_cur_max * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
+                    T.end(ev, K_SHADOW, st);
+                }
+                ev = T.begin(st);
+                launch_trace_closest(sc->view, n_cur_max, &w.counters.p->n_rays[nxt].v, nx.ray_o, nx.ray_d, nx.hit, st);
+                T.end(ev, K_CLOSEST, st);
+                cur = nxt;
+            }
+            HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            T.collect();
+            n_cur_max = w.h_counters->n_paths[cur].v;
+            continue;
+        }
         const int nxt = cur ^ 1;
         Wave cw = w.wave[cur].view(), nx = w.wave[nxt].view();
-        // (the counters of list `nxt` and the work-list lengths were cleared by launch_reset_counters of the
-        // previous iteration, or by k_init_free)
+        // (the counters indexed `nxt` were cleared by the previous iteration's k_bookkeep, or by k_init_free)
         int ev = T.begin(st);
         launch_shade(sc->view, C, cw, nx, w.scratch(), cur, n_cur_max, st);
         T.end(ev, K_SHADE, st);
@@ -329,19 +362,14 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
         HIP_TRY(hipStreamSynchronize(st));
         T.collect();
         const uint32_t n_next = w.h_counters->n_paths[nxt].v, n_cont = w.h_counters->n_rays[nxt].v;
-        const uint32_t n_free = w.h_counters->n_free.v, n_direct = w.h_counters->n_direct.v;
-        tot.direct += n_direct;
-        tot.iterations++;
-        tot.shaded += n_next;
-        tot.shadow += w.h_counters->n_shadow.v;  // shadow queue length of the previous iteration
+        const uint32_t n_free = w.h_counters->n_free.v, n_direct = w.h_counters->n_direct[nxt].v;
 
         // fork: everything below only depends on k_shade, which has completed (the host just synchronised on it)
         hipStream_t s_close = ctx.side[0] ? ctx.side[0] : st, s_prim = ctx.side[1] ? ctx.side[1] : st;
         if (n_cont > 0) {
             ev = T.begin(s_close);
-            launch_trace_closest(sc->view, n_cont, nx.ray_o, nx.ray_d, nx.hit, s_close);
+            launch_trace_closest(sc->view, n_cont, nullptr, nx.ray_o, nx.ray_d, nx.hit, s_close);
             T.end(ev, K_CLOSEST, s_close);
-            tot.closest += n_cont;
         }
         uint32_t g = 0;
         if (C.mode == 0 && next_work < n_work) {
@@ -352,14 +380,14 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             next_work += g;
             tot.closest += g;
         }
-        launch_reset_counters(w.counters.p, cur, st);  // list `cur` is consumed: it is the next iteration's output
+        launch_bookkeep(w.counters.p, cur, true, n_next, n_cont, n_direct, st);  // totals += lengths; list `cur` is consumed
         if (n_direct > 0) {
             ev = T.begin(st);
-            launch_direct(sc->view, C, nx, w.scratch(), n_direct, st);
+            launch_direct(sc->view, C, nx, w.scratch(), nxt, n_direct, st);
             T.end(ev, K_DIRECT, st);
             if (C.enable_shadow) {
                 ev = T.begin(st);
-                launch_trace_shadow(sc->view, w.counters.p, n_direct * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
+                launch_trace_shadow(sc->view, w.counters.p, nxt, n_direct * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
                 T.end(ev, K_SHADOW, st);
             }
         }
@@ -372,10 +400,18 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
         n_cur_max = n_next + 3 * g;
         cur = nxt;
     }
+    // the last shadow queue was consumed after the last k_bookkeep: fold it into the totals
+    HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     T.collect();
-    ctx.pushes += w.h_counters->pushes.v;
-    ctx.overflow += w.h_counters->overflow.v;
+    const Counters &hc = *w.h_counters;
+    ctx.pushes += hc.pushes.v;
+    ctx.overflow += hc.overflow.v;
+    tot.iterations += hc.tot_iterations;
+    tot.shaded += hc.tot_shaded;
+    tot.direct += hc.tot_direct;
+    tot.closest += hc.tot_cont;
+    tot.shadow += hc.tot_shadow + hc.n_shadow[0].v + hc.n_shadow[1].v;
     return MCPT_OK;
 }
 
@@ -717,7 +753,7 @@ int mcpt_intersect(mcpt_scene *sc, int64_t n, const float *origins, const float 
     HIP_TRY(upload(dO, o));
     HIP_TRY(upload(dD, d));
     HIP_TRY(dH.alloc(n));
-    launch_trace_closest(sc->view, (uint32_t)n, dO.p, dD.p, dH.p, nullptr);
+    launch_trace_closest(sc->view, (uint32_t)n, nullptr, dO.p, dD.p, dH.p, nullptr);
     std::vector<uint4> h(n);
     const hipError_t e = hipMemcpy(h.data(), dH.p, n * sizeof(uint4), hipMemcpyDeviceToHost);
     dO.release(); dD.release(); dH.release();

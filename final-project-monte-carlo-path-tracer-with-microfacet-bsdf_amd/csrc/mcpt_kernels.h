@@ -21,11 +21,13 @@ struct alignas(128) HotCounter {
 struct Counters {
     HotCounter n_paths[2];  // records in path list 0 / 1
     HotCounter n_rays[2];   // entries in closest-hit queue 0 / 1
-    HotCounter n_shadow;    // entries in the shadow-ray queue of the current iteration
-    HotCounter n_direct;    // vertices of the current iteration that need direct lighting (k_direct work list)
+    HotCounter n_shadow[2]; // entries in the shadow-ray queue (indexed like the list the rays belong to)
+    HotCounter n_direct[2]; // vertices that need direct lighting: length of the k_direct work list (same indexing)
     HotCounter n_free;      // entries in the free-slot stack
     HotCounter pushes;      // cumulative: recursion levels entered (castRay depth+1 calls)
     HotCounter overflow;    // cumulative: paths cut by max_depth
+    // cumulative totals kept on the device by k_bookkeep (the host does not see every iteration's counts)
+    unsigned long long tot_shaded, tot_direct, tot_shadow, tot_cont, tot_iterations;
 };
 
 // One side of the double-buffered wavefront state (all SoA, 16-byte records, indexed by list position).
@@ -74,9 +76,9 @@ struct CameraConst {
 };
 
 void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, hipStream_t s);
-// After k_shade(cur -> next) has completed and its counters were copied to the host: clears the counters of list
-// `cur` (the next iteration's output list) and the per-iteration work-list lengths, in one launch.
-void launch_reset_counters(Counters *c, int cur_idx, hipStream_t s);
+// After k_shade(cur -> next): adds this iteration's list lengths to the cumulative totals and clears the counters of
+// list `cur` (consumed; it is the next iteration's output list), in one launch.
+void launch_bookkeep(Counters *c, int cur_idx, bool from_host, uint32_t n_next, uint32_t n_cont, uint32_t n_direct, hipStream_t s);
 // Camera ray + closest hit for `n_samples` new samples, fused: a miss or a depth-0 emitter hit writes the
 // three channel results directly; any other hit appends one ray/hit entry and three fresh path records to
 // wave `next` (list index `next_idx`).
@@ -85,12 +87,15 @@ void launch_primary(const DevScene &S, const CameraConst &cam, const RenderConst
 void launch_generate_explicit(const RenderConst &C, Wave next, int next_idx, uint32_t n, hipStream_t s);
 void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const uint32_t *pixel, const uint32_t *sample,
                         float4 *o, float4 *d, hipStream_t s);
-void launch_trace_closest(const DevScene &S, uint32_t n, const float4 *ray_o, const float4 *ray_d, uint4 *hit, hipStream_t s);
+// n_dev != nullptr: the ray count is read on the device (n is then only the grid's upper bound).
+void launch_trace_closest(const DevScene &S, uint32_t n, const uint32_t *n_dev, const float4 *ray_o, const float4 *ray_d, uint4 *hit,
+                          hipStream_t s);
 // Direct lighting (Scene::directLighting, Scene.cpp:56-82) for the n_vertices entries of the k_direct work list:
 // one lane per (vertex, light sample); fills next.contrib and appends the non-zero samples to the shadow queue.
-void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, uint32_t n_vertices, hipStream_t s);
+void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_max, hipStream_t s);
 // Shadow queue (length in counters->n_shadow, at most n_max): zeroes contrib[] of invisible samples.
-void launch_trace_shadow(const DevScene &S, const Counters *counters, uint32_t n_max, Scratch X, float *contrib, hipStream_t s);
+void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, Scratch X, float *contrib,
+                         hipStream_t s);
 // Shades list `cur_idx` (at most n_cur_max records; the true count is read from the device counter) into the other list.
 void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, Scratch X, int cur_idx, uint32_t n_cur_max,
                   hipStream_t s);

@@ -269,11 +269,13 @@ MCPT_DI uint4 pack_hit(double t, int32_t prim, uint32_t mat_bits) {  // {t lo, t
 }
 
 template <int STK>
-__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n, const float4 *__restrict__ ray_o,
-                                                          const float4 *__restrict__ ray_d, uint4 *__restrict__ hit) {
+__global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n_host, const uint32_t *__restrict__ n_dev,
+                                                          const float4 *__restrict__ ray_o, const float4 *__restrict__ ray_d,
+                                                          uint4 *__restrict__ hit) {
     __shared__ int32_t stk[STK][kBlock];
     const int tid = threadIdx.x;
     const uint32_t i = blockIdx.x * kBlock + tid;
+    const uint32_t n = n_dev ? *n_dev : n_host;
     if (i >= n) return;
     const Ray r = make_ray(ld3(ray_o[i]), ld3(ray_d[i]));
     const TraceResult tr = traverse<false, STK>(S, r, 0.f, stk, tid);
@@ -282,12 +284,12 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n
 
 // Shadow queue consumer: a fixed grid strides over the queue, whose length is only known on the device.
 template <int STK>
-__global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Counters *__restrict__ counters,
+__global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Counters *__restrict__ counters, int next_idx,
                                                          const float4 *__restrict__ shq_o, const float4 *__restrict__ shq_d,
                                                          float *__restrict__ contrib) {
     __shared__ int32_t stk[STK][kBlock];
     const int tid = threadIdx.x;
-    const uint32_t n = counters->n_shadow.v;
+    const uint32_t n = counters->n_shadow[next_idx].v;
     for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += gridDim.x * kBlock) {
         const float4 o = shq_o[i], d = shq_d[i];
         const Ray r = make_ray(ld3(o), ld3(d));
@@ -445,10 +447,11 @@ __global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Coun
         c->n_paths[0].v = c->n_paths[1].v = 0;
         c->n_rays[0].v = c->n_rays[1].v = 0;
         c->n_free.v = pool;
-        c->n_shadow.v = 0;
-        c->n_direct.v = 0;
+        c->n_shadow[0].v = c->n_shadow[1].v = 0;
+        c->n_direct[0].v = c->n_direct[1].v = 0;
         c->pushes.v = 0;
         c->overflow.v = 0;
+        c->tot_shaded = c->tot_direct = c->tot_shadow = c->tot_cont = c->tot_iterations = 0;
     }
 }
 
@@ -702,7 +705,7 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     const bool want[6] = {finished, do_shade, has_cont, need_direct, pushed, overflow};
     const uint32_t mult[6] = {1u, 1u, 1u, 1u, 1u, 1u};
     uint32_t *const ctr[6] = {&C.counters->n_free.v, &C.counters->n_paths[next_idx].v, &C.counters->n_rays[next_idx].v,
-                              &C.counters->n_direct.v, &C.counters->pushes.v, &C.counters->overflow.v};
+                              &C.counters->n_direct[next_idx].v, &C.counters->pushes.v, &C.counters->overflow.v};
     const bool sub[6] = {false, false, false, false, false, false};
     uint32_t prefix[6], idx[6];
     block_alloc_begin<6>(sh, want, mult, ctr, sub, prefix);
@@ -758,10 +761,11 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
 // adds nothing to l_dir whether it is visible or not, so it casts no shadow ray; a NaN contribution is not zero
 // and is traced.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wave next, Scratch Xs, uint32_t n_vertices) {
+__global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wave next, Scratch Xs, int next_idx) {
     __shared__ BlockAllocShared sh;
     const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t n_dir = (uint32_t)C.n_dir;
+    const uint32_t n_vertices = C.counters->n_direct[next_idx].v;  // the grid is an upper bound
     const bool valid = g < n_vertices * n_dir;
     bool cast = false;
     f3 q = mk3(0, 0, 0), ws = mk3(0, 0, 1);
@@ -803,7 +807,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wa
     }
     const bool want[1] = {cast};
     const uint32_t mult[1] = {1u};
-    uint32_t *const ctr[1] = {&C.counters->n_shadow.v};
+    uint32_t *const ctr[1] = {&C.counters->n_shadow[next_idx].v};
     const bool sub[1] = {false};
     uint32_t idx[1];
     block_alloc<1>(sh, want, mult, ctr, sub, idx);
@@ -832,17 +836,28 @@ inline uint32_t blocks(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 }  // namespace
 
-__global__ void k_reset_counters(Counters *c, int cur_idx) {
+// Runs after k_shade(cur -> next).  List `cur` and everything indexed like it (its closest-hit queue, k_direct work
+// list and shadow queue, all produced one iteration earlier) are consumed: their lengths go to the totals and are
+// cleared, because `cur` is the next iteration's output list.
+// In the regular schedule k_primary may already be appending fresh records to list `next` on another stream, so the host
+// passes the lengths it read right after k_shade (from_host); in the drain phase they are read here.
+__global__ void k_bookkeep(Counters *c, int cur_idx, int from_host, uint32_t n_next, uint32_t n_cont, uint32_t n_direct) {
     if (threadIdx.x == 0) {
+        const int nxt = cur_idx ^ 1;
+        c->tot_shadow += c->n_shadow[cur_idx].v;
+        c->tot_shaded += from_host ? n_next : c->n_paths[nxt].v;
+        c->tot_cont += from_host ? n_cont : c->n_rays[nxt].v;
+        c->tot_direct += from_host ? n_direct : c->n_direct[nxt].v;
+        c->tot_iterations += 1;
         c->n_paths[cur_idx].v = 0;
         c->n_rays[cur_idx].v = 0;
-        c->n_direct.v = 0;
-        c->n_shadow.v = 0;
+        c->n_direct[cur_idx].v = 0;
+        c->n_shadow[cur_idx].v = 0;
     }
 }
 
-void launch_reset_counters(Counters *c, int cur_idx, hipStream_t s) {
-    hipLaunchKernelGGL(k_reset_counters, dim3(1), dim3(64), 0, s, c, cur_idx);
+void launch_bookkeep(Counters *c, int cur_idx, bool from_host, uint32_t n_next, uint32_t n_cont, uint32_t n_direct, hipStream_t s) {
+    hipLaunchKernelGGL(k_bookkeep, dim3(1), dim3(64), 0, s, c, cur_idx, from_host ? 1 : 0, n_next, n_cont, n_direct);
 }
 
 void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, hipStream_t s) {
@@ -871,21 +886,23 @@ void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const
 }
 
 // The LDS stack depth is picked from the scene's tree height (one pushed reference per level at most).
-void launch_trace_closest(const DevScene &S, uint32_t n, const float4 *ray_o, const float4 *ray_d, uint4 *hit, hipStream_t s) {
+void launch_trace_closest(const DevScene &S, uint32_t n, const uint32_t *n_dev, const float4 *ray_o, const float4 *ray_d, uint4 *hit,
+                          hipStream_t s) {
     if (n == 0) return;
     const dim3 g(blocks(n)), b(kBlock);
-    if (S.height <= 16) hipLaunchKernelGGL((k_trace_closest<16>), g, b, 0, s, S, n, ray_o, ray_d, hit);
-    else if (S.height <= 24) hipLaunchKernelGGL((k_trace_closest<24>), g, b, 0, s, S, n, ray_o, ray_d, hit);
-    else if (S.height <= 32) hipLaunchKernelGGL((k_trace_closest<32>), g, b, 0, s, S, n, ray_o, ray_d, hit);
-    else hipLaunchKernelGGL((k_trace_closest<kMaxBvhHeight>), g, b, 0, s, S, n, ray_o, ray_d, hit);
+    if (S.height <= 16) hipLaunchKernelGGL((k_trace_closest<16>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
+    else if (S.height <= 24) hipLaunchKernelGGL((k_trace_closest<24>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
+    else if (S.height <= 32) hipLaunchKernelGGL((k_trace_closest<32>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
+    else hipLaunchKernelGGL((k_trace_closest<kMaxBvhHeight>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
 }
 
-void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, uint32_t n_vertices, hipStream_t s) {
-    if (n_vertices == 0) return;
-    hipLaunchKernelGGL(k_direct, dim3(blocks(n_vertices * (uint32_t)C.n_dir)), dim3(kBlock), 0, s, S, C, next, X, n_vertices);
+void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_max, hipStream_t s) {
+    if (n_vertices_max == 0) return;
+    hipLaunchKernelGGL(k_direct, dim3(blocks(n_vertices_max * (uint32_t)C.n_dir)), dim3(kBlock), 0, s, S, C, next, X, next_idx);
 }
 
-void launch_trace_shadow(const DevScene &S, const Counters *counters, uint32_t n_max, Scratch X, float *contrib, hipStream_t s) {
+void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, Scratch X, float *contrib,
+                         hipStream_t s) {
     if (n_max == 0) return;
     // The queue length is only known on the device.  The grid covers the upper bound (capped at 1024 workgroups per
     // CU, far more than are resident, so the hardware balances uneven rays dynamically: a persistent 8-per-CU grid
@@ -894,10 +911,10 @@ void launch_trace_shadow(const DevScene &S, const Counters *counters, uint32_t n
     const char *cap_env = std::getenv("MCPT_SHADOW_GRID_PER_CU");
     const uint32_t per_cu = cap_env ? (uint32_t)std::max(1, std::atoi(cap_env)) : 1024u;
     const dim3 g(std::min<uint32_t>(blocks(n_max), 256u * per_cu)), b(kBlock);
-    if (stk == 16) hipLaunchKernelGGL((k_trace_shadow<16>), g, b, 0, s, S, counters, X.shq_o, X.shq_d, contrib);
-    else if (stk == 24) hipLaunchKernelGGL((k_trace_shadow<24>), g, b, 0, s, S, counters, X.shq_o, X.shq_d, contrib);
-    else if (stk == 32) hipLaunchKernelGGL((k_trace_shadow<32>), g, b, 0, s, S, counters, X.shq_o, X.shq_d, contrib);
-    else hipLaunchKernelGGL((k_trace_shadow<kMaxBvhHeight>), g, b, 0, s, S, counters, X.shq_o, X.shq_d, contrib);
+    if (stk == 16) hipLaunchKernelGGL((k_trace_shadow<16>), g, b, 0, s, S, counters, next_idx, X.shq_o, X.shq_d, contrib);
+    else if (stk == 24) hipLaunchKernelGGL((k_trace_shadow<24>), g, b, 0, s, S, counters, next_idx, X.shq_o, X.shq_d, contrib);
+    else if (stk == 32) hipLaunchKernelGGL((k_trace_shadow<32>), g, b, 0, s, S, counters, next_idx, X.shq_o, X.shq_d, contrib);
+    else hipLaunchKernelGGL((k_trace_shadow<kMaxBvhHeight>), g, b, 0, s, S, counters, next_idx, X.shq_o, X.shq_d, contrib);
 }
 
 void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, Scratch X, int cur_idx, uint32_t n_cur_max,
