@@ -7,7 +7,10 @@ n_dir_sample = 4 as the reference executes; pass --n-dir 32 for the README's lab
 
 A "step" is one pass of --spp-per-step samples per pixel over the whole frame, accumulated into the
 device framebuffer (progressive rendering: K steps = K*spp_per_step spp of the same frame).  The defaults
-(8 steps x 256 spp) are the full 1920x1080, spp = 2048 frame the metric is quoted on.  The scene
+(8 steps x 256 spp) are the full 1920x1080, spp = 2048 frame the metric is quoted on.  The K timed steps are
+issued as ONE mcpt_render_device call with spp = K*spp_per_step and spp_per_pass = spp_per_step: the library keeps
+two passes in flight, so the drain tail of a step overlaps the start of the next one (--per-step-calls issues one
+call per step instead).  The scene
 is resident in HBM before the timed region.  With N ranks the frame is partitioned into interleaved
 32x32 pixel tiles (strong scaling: the frame is fixed), every rank renders its tiles, and the timed
 region ends with one RCCL reduce of the framebuffer to rank 0 (torch.distributed, backend nccl).
@@ -48,6 +51,7 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device rehearses the N>1 path on a one-GPU box (the reduce goes through host memory)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--per-step-calls", action="store_true", help="one library call per step (drains between steps)")
     return ap.parse_args()
 
 
@@ -132,8 +136,8 @@ def main():
     spp_step = args.spp_per_step
     total_spp = spp_step * args.steps
 
-    def step(k, spp_total, accumulate):
-        return hs.render_device(fb.data_ptr(), stream.cuda_stream, spp=spp_step, spp_total=spp_total,
+    def step(k, spp_total, accumulate, n_steps=1):
+        return hs.render_device(fb.data_ptr(), stream.cuda_stream, spp=spp_step * n_steps, spp_total=spp_total,
                                 sample_offset=k * spp_step, accumulate=accumulate, seed=1, tile_size=32,
                                 rank=rank, nranks=world, n_dir_sample=args.n_dir, spp_per_pass=spp_step,
                                 pool_paths=args.pool_paths)
@@ -143,8 +147,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
-        step(k, max(1, args.warmup * spp_step), 1 if k else 0)
+    if args.warmup:
+        step(0, max(1, args.warmup * spp_step), 0, n_steps=args.warmup)
     if distributed and args.warmup:
         reduce_to_rank0(fb)
     fb.zero_()
@@ -152,10 +156,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     agg = None
-    for k in range(args.steps):
-        st = step(k, total_spp, 1)
-        d = st.as_dict()
-        agg = d if agg is None else {key: agg[key] + d[key] for key in d}
+    if args.per_step_calls:
+        for k in range(args.steps):
+            d = step(k, total_spp, 1).as_dict()
+            agg = d if agg is None else {key: agg[key] + d[key] for key in d}
+    else:
+        agg = step(0, total_spp, 1, n_steps=args.steps).as_dict()
     if distributed:
         reduce_to_rank0(fb)  # RCCL framebuffer merge over xGMI, inside the timed region
     barrier()

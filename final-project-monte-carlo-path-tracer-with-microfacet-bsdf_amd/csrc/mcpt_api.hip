@@ -276,10 +276,28 @@ struct LoopTotals {
     uint64_t iterations = 0, shaded = 0, closest = 0, shadow = 0, direct = 0;
 };
 
-// Runs the wavefront loop until `n_work` units (camera samples in mode 0, explicit paths in mode 1) are
-// done.  `result` receives one float per path id.
-int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const CameraConst *cam, uint32_t first_work,
-                  uint32_t n_work, hipStream_t st, LoopTotals &tot) {
+// One pass of a render call: `n_work` camera samples whose results live in one half of the result buffer.
+struct PassPlan {
+    uint32_t first_work;  // first sample slot of the pass handled by this pool
+    uint32_t n_work;      // sample slots handled by this pool
+    int32_t s_pass, sample_offset;
+};
+
+// Where finished passes go.  acc == nullptr: the caller accumulates (single pass only).
+struct AccumPlan {
+    float *fb;
+    float spp_total;
+    uint32_t n_pix;
+    const uint32_t *pixel_list;
+    float *result[2];
+};
+
+// Runs the wavefront loop over a schedule of passes (mode 0) or over `plan[0].n_work` explicit paths (mode 1).
+// Up to two passes are in flight: as soon as a pass has no samples left to issue, the next one starts filling the pool,
+// so the drain tail of a pass overlaps useful work.  A pass is complete when its live-path counter is 0 (and all its
+// samples were issued at least one iteration ago); passes are accumulated into the framebuffer strictly in order.
+int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const CameraConst *cam, const std::vector<PassPlan> &plan,
+                  const AccumPlan *acc, hipStream_t st, LoopTotals &tot) {
     Workspace &w = ctx.ws;
     Timer &T = ctx.timer;
     RenderConst C = C0;
@@ -289,44 +307,91 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     C.counters = w.counters.p;
     const uint32_t pool = w.pool;
     const int n_dir = C.n_dir;
+    const int P = (int)plan.size();
+    C.track_live = (acc && P > 1) ? 1 : 0;
     launch_init_free(w.free_slots.p, w.counters.p, pool, st);
-    uint32_t next_work = 0;
     int cur = 0;
     uint32_t n_cur_max = 0;  // upper bound of the record count of wave[cur] (the exact count lives on the device)
+    int issue_pass = 0, accum_next = 0;
+    uint32_t issued = 0;
+    long it = 0;
+    std::vector<long> issue_done_iter(P, -1);
+    hipStream_t s_close = ctx.side[0] ? ctx.side[0] : st, s_prim = ctx.side[1] ? ctx.side[1] : st;
+
+    auto set_pass_consts = [&](int pi) {  // kernel constants of the pass occupying parity pi & 1
+        C.s_pass[pi & 1] = plan[pi].s_pass;
+        C.sample_offset[pi & 1] = plan[pi].sample_offset;
+    };
+    // issues up to `room` new samples from the passes that may be in flight; returns how many
+    auto issue = [&](Wave nx, int nxt, uint32_t room) -> uint32_t {
+        uint32_t total = 0;
+        while (room > 0 && issue_pass < P && (!acc || issue_pass < accum_next + 2)) {
+            if (issued == 0) set_pass_consts(issue_pass);
+            const uint32_t g = std::min<uint32_t>(room, plan[issue_pass].n_work - issued);
+            if (g > 0) {
+                int ev = T.begin(s_prim);
+                launch_primary(sc->view, *cam, C, nx, nxt, issue_pass & 1, plan[issue_pass].first_work + issued, g, s_prim);
+                T.end(ev, K_GENERATE, s_prim);
+                tot.closest += g;
+            }
+            issued += g;
+            room -= g;
+            total += g;
+            if (issued == plan[issue_pass].n_work) {
+                issue_done_iter[issue_pass] = it;
+                issue_pass++;
+                issued = 0;
+            } else {
+                break;
+            }
+        }
+        return total;
+    };
+    // accumulates, in order, every pass that is complete according to the counters just read back
+    auto accumulate_done = [&](hipStream_t s) {
+        while (acc && accum_next < issue_pass && issue_done_iter[accum_next] < it &&
+               (C.track_live ? w.h_counters->live[accum_next & 1].v == 0 : (n_cur_max == 0 && issue_pass >= P))) {
+            int ev = T.begin(s);
+            launch_accumulate(acc->result[accum_next & 1], acc->pixel_list, acc->n_pix, plan[accum_next].s_pass, acc->spp_total, acc->fb, s);
+            T.end(ev, K_RESOLVE, s);
+            accum_next++;
+        }
+    };
 
     // prologue: fill the pool
     {
         Wave nx = w.wave[cur].view();
         if (C.mode == 0) {
-            const uint32_t g = std::min<uint32_t>(n_work, pool / 3);
-            int ev = T.begin(st);
-            launch_primary(sc->view, *cam, C, nx, cur, first_work, g, st);
-            T.end(ev, K_GENERATE, st);
-            next_work = g;
-            n_cur_max = 3 * g;
-            tot.closest += g;
+            n_cur_max = 3 * issue(nx, cur, pool / 3);
         } else {
             // explicit rays were uploaded into wave[cur].ray_o/ray_d by the caller
+            const uint32_t n_work = plan[0].n_work;
             launch_generate_explicit(C, nx, cur, n_work, st);
-            next_work = n_work;
+            issue_pass = P;
             n_cur_max = n_work;
             int ev = T.begin(st);
             launch_trace_closest(sc->view, n_work, nullptr, nx.ray_o, nx.ray_d, nx.hit, st);
             T.end(ev, K_CLOSEST, st);
             tot.closest += n_work;
         }
+        for (int k = 0; k < 2; ++k) {  // join the side streams before the first k_shade
+            if (!ctx.side[k]) continue;
+            HIP_TRY(hipEventRecord(ctx.join[k], ctx.side[k]));
+            HIP_TRY(hipStreamWaitEvent(st, ctx.join[k], 0));
+        }
     }
 
     const char *db = std::getenv("MCPT_DRAIN_BATCH");  // iterations queued per host sync once no samples are left to issue
     const int drain_batch = db ? std::max(1, std::atoi(db)) : 4;
-    while (n_cur_max > 0) {
+    while (n_cur_max > 0 || issue_pass < P || (acc && accum_next < P)) {
+        ++it;
         // (big lists keep the three-stream schedule with exact launch sizes: over-sized grids only pay off when small)
-        const bool draining = ((C.mode != 0) || next_work >= n_work) && n_cur_max <= (2u << 20);
+        const bool draining = issue_pass >= P && n_cur_max > 0 && n_cur_max <= (2u << 20);
         if (draining && drain_batch > 1) {
             // Drain phase: no regeneration, so list lengths only shrink.  Several iterations are queued back to back
             // on one stream with the last known length as the grid bound (every kernel reads the true lengths on the
             // device); the host looks at the counters once per batch.
-            for (int it = 0; it < drain_batch; ++it) {
+            for (int k = 0; k < drain_batch; ++k) {
                 const int nxt = cur ^ 1;
                 Wave cw = w.wave[cur].view(), nx = w.wave[nxt].view();
                 int ev = T.begin(st);
@@ -350,14 +415,18 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             HIP_TRY(hipStreamSynchronize(st));
             T.collect();
             n_cur_max = w.h_counters->n_paths[cur].v;
+            accumulate_done(st);
             continue;
         }
         const int nxt = cur ^ 1;
         Wave cw = w.wave[cur].view(), nx = w.wave[nxt].view();
         // (the counters indexed `nxt` were cleared by the previous iteration's k_bookkeep, or by k_init_free)
-        int ev = T.begin(st);
-        launch_shade(sc->view, C, cw, nx, w.scratch(), cur, n_cur_max, st);
-        T.end(ev, K_SHADE, st);
+        int ev = -1;
+        if (n_cur_max > 0) {
+            ev = T.begin(st);
+            launch_shade(sc->view, C, cw, nx, w.scratch(), cur, n_cur_max, st);
+            T.end(ev, K_SHADE, st);
+        }
         HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         T.collect();
@@ -365,21 +434,14 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
         const uint32_t n_free = w.h_counters->n_free.v, n_direct = w.h_counters->n_direct[nxt].v;
 
         // fork: everything below only depends on k_shade, which has completed (the host just synchronised on it)
-        hipStream_t s_close = ctx.side[0] ? ctx.side[0] : st, s_prim = ctx.side[1] ? ctx.side[1] : st;
         if (n_cont > 0) {
             ev = T.begin(s_close);
             launch_trace_closest(sc->view, n_cont, nullptr, nx.ray_o, nx.ray_d, nx.hit, s_close);
             T.end(ev, K_CLOSEST, s_close);
         }
+        accumulate_done(s_prim);  // frees the result half that the pass after next needs; ordered before its k_primary
         uint32_t g = 0;
-        if (C.mode == 0 && next_work < n_work) {
-            g = std::min<uint32_t>(n_work - next_work, std::min<uint32_t>((pool - n_next) / 3, n_free / 3));
-            ev = T.begin(s_prim);
-            launch_primary(sc->view, *cam, C, nx, nxt, first_work + next_work, g, s_prim);
-            T.end(ev, K_GENERATE, s_prim);
-            next_work += g;
-            tot.closest += g;
-        }
+        if (C.mode == 0) g = issue(nx, nxt, std::min<uint32_t>((pool - n_next) / 3, n_free / 3));
         launch_bookkeep(w.counters.p, cur, true, n_next, n_cont, n_direct, st);  // totals += lengths; list `cur` is consumed
         if (n_direct > 0) {
             ev = T.begin(st);
@@ -462,7 +524,10 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
         return MCPT_OK;
     }
     for (int k = 0; k < n_pools; ++k) HIP_TRY(ensure_workspace(sc->pools[k], pool, p.n_dir_sample, max_depth));
-    HIP_TRY(sh.result.alloc((size_t)n_pix * s_pass * 3));
+    // two halves: a pass accumulates from one while the next pass fills the other (one half with a single pass)
+    const size_t half_floats = (size_t)n_pix * s_pass * 3;
+    const bool two_halves = n_pools == 1 && p.spp > s_pass;
+    HIP_TRY(sh.result.alloc(half_floats * (two_halves ? 2 : 1)));
 
     RenderConst C;
     std::memset(&C, 0, sizeof C);
@@ -474,7 +539,8 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     C.mode = 0;
     C.pixel_list = sh.pixel_list.p;
     C.max_depth = max_depth;
-    C.result = sh.result.p;
+    C.result[0] = sh.result.p;
+    C.result[1] = two_halves ? sh.result.p + half_floats : sh.result.p;
     const CameraConst cc = make_camera(*cam);
     const float spp_total = (float)(p.spp_total > 0 ? p.spp_total : p.spp);
 
@@ -485,40 +551,47 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
         sc->pools[k].pushes = sc->pools[k].overflow = 0;
     }
     LoopTotals tot[mcpt_scene::kMaxPools];
-    for (int k0 = 0; k0 < p.spp; k0 += s_pass) {
-        const int s_now = std::min(s_pass, p.spp - k0);
-        C.s_pass = s_now;
-        C.sample_offset = p.sample_offset + k0;
-        const uint32_t n_work = n_pix * (uint32_t)s_now;
-        if (n_pools == 1) {
-            const int rc = run_wavefront(sc, sc->pools[0], C, &cc, 0, n_work, st, tot[0]);
-            if (rc != MCPT_OK) return rc;
-        } else {
+    if (n_pools == 1) {
+        // one pool: all passes of the call go through one pipelined schedule
+        std::vector<PassPlan> plan;
+        for (int k0 = 0; k0 < p.spp; k0 += s_pass) {
+            const int s_now = std::min(s_pass, p.spp - k0);
+            plan.push_back(PassPlan{0u, n_pix * (uint32_t)s_now, s_now, p.sample_offset + k0});
+        }
+        AccumPlan acc{fb_dev, spp_total, n_pix, sh.pixel_list.p, {C.result[0], C.result[1]}};
+        const int rc = run_wavefront(sc, sc->pools[0], C, &cc, plan, &acc, st, tot[0]);
+        if (rc != MCPT_OK) return rc;
+    } else {
+        for (int k0 = 0; k0 < p.spp; k0 += s_pass) {
+            const int s_now = std::min(s_pass, p.spp - k0);
+            const uint32_t n_work = n_pix * (uint32_t)s_now;
             // pool 1 (own stream, own host thread) takes the second half of the pass; it starts after the
-            // framebuffer clear / pixel-list upload queued on the caller's stream
+            // framebuffer clear / pixel-list upload / previous accumulate queued on the caller's stream
             const uint32_t half = n_work / 2;
             HIP_TRY(hipEventRecord(sc->fork, st));
             PoolCtx &c1 = sc->pools[1];
             HIP_TRY(hipStreamWaitEvent(c1.main, sc->fork, 0));
             c1.rc = MCPT_OK;
+            const std::vector<PassPlan> plan0{PassPlan{0u, half, s_now, p.sample_offset + k0}};
+            const std::vector<PassPlan> plan1{PassPlan{half, n_work - half, s_now, p.sample_offset + k0}};
             std::thread worker([&]() {
                 if (hipSetDevice(sc->device) != hipSuccess) {
                     c1.rc = MCPT_ERR_HIP;
                     c1.err = "hipSetDevice failed in the pool thread";
                     return;
                 }
-                c1.rc = run_wavefront(sc, c1, C, &cc, half, n_work - half, c1.main, tot[1]);
+                c1.rc = run_wavefront(sc, c1, C, &cc, plan1, nullptr, c1.main, tot[1]);
                 if (c1.rc != MCPT_OK) c1.err = g_err;
             });
-            const int rc0 = run_wavefront(sc, sc->pools[0], C, &cc, 0, half, st, tot[0]);
+            const int rc0 = run_wavefront(sc, sc->pools[0], C, &cc, plan0, nullptr, st, tot[0]);
             worker.join();  // run_wavefront ends with a stream synchronise: both halves are complete here
             if (rc0 != MCPT_OK) return rc0;
             if (c1.rc != MCPT_OK) return fail(c1.rc, c1.err);
+            Timer &T0 = sc->pools[0].timer;
+            int ev = T0.begin(st);
+            launch_accumulate(C.result[0], sh.pixel_list.p, n_pix, s_now, spp_total, fb_dev, st);
+            T0.end(ev, K_RESOLVE, st);
         }
-        Timer &T0 = sc->pools[0].timer;
-        int ev = T0.begin(st);
-        launch_accumulate(sh.result.p, sh.pixel_list.p, n_pix, s_now, spp_total, fb_dev, st);
-        T0.end(ev, K_RESOLVE, st);
     }
     HIP_TRY(hipStreamSynchronize(st));
     sc->pools[0].timer.collect();
@@ -816,9 +889,10 @@ int mcpt_cast_rays(mcpt_scene *sc, const mcpt_params *pp, int64_t n, const float
         C.key_sample = sh.key_sample.p;
         C.key_channel = sh.key_channel.p;
         C.max_depth = w.max_depth;
-        C.result = sh.result.p;
+        C.result[0] = C.result[1] = sh.result.p;
         LoopTotals tot;
-        const int rc = run_wavefront(sc, ctx, C, nullptr, 0, m, nullptr, tot);
+        const std::vector<PassPlan> plan{PassPlan{0u, m, 1, 0}};
+        const int rc = run_wavefront(sc, ctx, C, nullptr, plan, nullptr, nullptr, tot);
         if (rc != MCPT_OK) return rc;
         HIP_TRY(hipMemcpy(out + base, sh.result.p, m * sizeof(float), hipMemcpyDeviceToHost));
     }

@@ -10,6 +10,7 @@ namespace mcpt {
 constexpr uint32_t kFresh = 1u << 16;      // no pending vertex: the record's ray is the path's first ray
 constexpr uint32_t kTerminate = 1u << 17;  // Russian roulette failed at the pending vertex (Scene.cpp:129,156)
 constexpr uint32_t kInside = 1u << 18;     // wo.n < 0 at the pending vertex (Scene.cpp:115)
+constexpr uint32_t kPassBit = 1u << 20;    // which of the two passes in flight the path belongs to (pass index & 1)
 constexpr uint32_t kNoDirect = 1u << 19;   // every light sample of the pending vertex contributes exactly 0: contrib[] not written
 
 // Device counters.  Every hot word sits on its own 128-byte line: the allocation atomics of different
@@ -24,6 +25,7 @@ struct Counters {
     HotCounter n_shadow[2]; // entries in the shadow-ray queue (indexed like the list the rays belong to)
     HotCounter n_direct[2]; // vertices that need direct lighting: length of the k_direct work list (same indexing)
     HotCounter n_free;      // entries in the free-slot stack
+    HotCounter live[2];     // unfinished paths of the pass with that parity (a pass is complete when it reaches 0)
     HotCounter pushes;      // cumulative: recursion levels entered (castRay depth+1 calls)
     HotCounter overflow;    // cumulative: paths cut by max_depth
     // cumulative totals kept on the device by k_bookkeep (the host does not see every iteration's counts)
@@ -57,13 +59,14 @@ struct RenderConst {
     uint32_t seed;
     int32_t mode;  // 0: pid -> (pixel list, sample); 1: explicit per-path keys (mcpt_cast_rays)
     const uint32_t *pixel_list;
-    int32_t s_pass, sample_offset;
+    int32_t s_pass[2], sample_offset[2];  // per pass parity: two passes can be in flight
     const uint32_t *key_pixel, *key_sample;
     const int32_t *key_channel;
     int32_t max_depth;
+    int32_t track_live;  // maintain Counters::live (only needed when several passes are pipelined)
     uint32_t pool;  // clamp-stack row length (slots)
     float4 *stack;  // [level][slot] = {clamp(0,15,l_dir), eval, |wo.n| or -1, pdf}
-    float *result;  // per pid: castRay(ray, 0, channel)
+    float *result[2];  // per pass parity, per pid: castRay(ray, 0, channel)
     uint32_t *free_slots;
     Counters *counters;
 };
@@ -82,7 +85,7 @@ void launch_bookkeep(Counters *c, int cur_idx, bool from_host, uint32_t n_next, 
 // Camera ray + closest hit for `n_samples` new samples, fused: a miss or a depth-0 emitter hit writes the
 // three channel results directly; any other hit appends one ray/hit entry and three fresh path records to
 // wave `next` (list index `next_idx`).
-void launch_primary(const DevScene &S, const CameraConst &cam, const RenderConst &C, Wave next, int next_idx,
+void launch_primary(const DevScene &S, const CameraConst &cam, const RenderConst &C, Wave next, int next_idx, int parity,
                     uint32_t first_sample, uint32_t n_samples, hipStream_t s);
 void launch_generate_explicit(const RenderConst &C, Wave next, int next_idx, uint32_t n, hipStream_t s);
 void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const uint32_t *pixel, const uint32_t *sample,

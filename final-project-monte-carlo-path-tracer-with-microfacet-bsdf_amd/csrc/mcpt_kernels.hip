@@ -36,7 +36,7 @@ MCPT_DI uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amd
 // workgroup (lane k of wave 0 adds the block total of request k), instead of one returning atomic per
 // wave and counter: the hot counters are the only cross-workgroup contention points of the pipeline.
 // Must be called by every thread of the block (it contains barriers).
-constexpr int kMaxAlloc = 6;
+constexpr int kMaxAlloc = 8;
 constexpr int kMaxWaves = 16;
 struct BlockAllocShared {
     uint32_t cnt[kMaxWaves][kMaxAlloc];
@@ -301,13 +301,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Count
 // ------------------------------------------------------------------------------------------------
 // Path keys
 // ------------------------------------------------------------------------------------------------
-MCPT_DI void path_key(const RenderConst &C, uint32_t pid, RngKey &key, int &ch) {
+MCPT_DI void path_key(const RenderConst &C, uint32_t pid, int q, RngKey &key, int &ch) {
     if (C.mode == 0) {
         ch = (int)(pid % 3u);
         const uint32_t s = pid / 3u;
-        const uint32_t pl = s / (uint32_t)C.s_pass;
+        const uint32_t sp = (uint32_t)(q ? C.s_pass[1] : C.s_pass[0]);
+        const uint32_t pl = s / sp;
         key.pixel = C.pixel_list ? C.pixel_list[pl] : pl;
-        key.sample = (uint32_t)C.sample_offset + (s % (uint32_t)C.s_pass);
+        key.sample = (uint32_t)(q ? C.sample_offset[1] : C.sample_offset[0]) + (s % sp);
     } else {
         ch = C.key_channel[pid];
         key.pixel = C.key_pixel[pid];
@@ -353,7 +354,7 @@ MCPT_DI void camera_ray(const CameraConst &cam, uint32_t seed, uint32_t m, uint3
 //   depth-0 emitter (Scene.cpp:102-107)  result[3 channels] = clamp(0,1, emission * |wo.n|), no records
 //   surface ........................... one ray + hit entry, three fresh path records, three clamp-stack slots
 template <int STK>
-__global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam, RenderConst C, Wave next, int next_idx,
+__global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam, RenderConst C, Wave next, int next_idx, int q,
                                                     uint32_t first_sample, uint32_t n_samples) {
     __shared__ int32_t stk[STK][kBlock];
     __shared__ BlockAllocShared sh;
@@ -364,18 +365,20 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
     bool surface = false;
     f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1);
     TraceResult tr{DBL_MAX, -1, 0u, false};
+    float *const result = q ? C.result[1] : C.result[0];
     if (valid) {
-        const uint32_t pl = s / (uint32_t)C.s_pass;
+        const uint32_t sp = (uint32_t)(q ? C.s_pass[1] : C.s_pass[0]);
+        const uint32_t pl = s / sp;
         const uint32_t m = C.pixel_list ? C.pixel_list[pl] : pl;
-        const uint32_t k = (uint32_t)C.sample_offset + (s % (uint32_t)C.s_pass);
+        const uint32_t k = (uint32_t)(q ? C.sample_offset[1] : C.sample_offset[0]) + (s % sp);
         camera_ray(cam, C.seed, m, k, pos, dir);
         const Ray r = make_ray(pos, dir);
         tr = traverse<false, STK>(S, r, 0.f, stk, tid);
         if (tr.prim < 0) {
             const f3 env = sample_env(S, dir);
-            C.result[(size_t)s * 3 + 0] = env.x;
-            C.result[(size_t)s * 3 + 1] = env.y;
-            C.result[(size_t)s * 3 + 2] = env.z;
+            result[(size_t)s * 3 + 0] = env.x;
+            result[(size_t)s * 3 + 1] = env.y;
+            result[(size_t)s * 3 + 2] = env.z;
         } else {
             const int mat = (int)(tr.mat_bits & 0x7fffffffu);
             if (tr.mat_bits >> 31) {  // depth-0 emitter, Scene.cpp:102-107
@@ -390,20 +393,21 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
                     n = normalized(p - mk3(sp.c[0], sp.c[1], sp.c[2]));
                 }
                 const float c = fabsf(dot(-dir, n));
-                C.result[(size_t)s * 3 + 0] = clampf(0, 1, M.emit[0] * c);
-                C.result[(size_t)s * 3 + 1] = clampf(0, 1, M.emit[1] * c);
-                C.result[(size_t)s * 3 + 2] = clampf(0, 1, M.emit[2] * c);
+                result[(size_t)s * 3 + 0] = clampf(0, 1, M.emit[0] * c);
+                result[(size_t)s * 3 + 1] = clampf(0, 1, M.emit[1] * c);
+                result[(size_t)s * 3 + 2] = clampf(0, 1, M.emit[2] * c);
             } else {
                 surface = true;
             }
         }
     }
-    const bool want[3] = {surface, surface, surface};
-    const uint32_t mult[3] = {1u, 3u, 3u};
-    uint32_t *const ctr[3] = {&C.counters->n_rays[next_idx].v, &C.counters->n_paths[next_idx].v, &C.counters->n_free.v};
-    const bool sub[3] = {false, false, true};
-    uint32_t idx[3];
-    block_alloc<3>(sh, want, mult, ctr, sub, idx);
+    const bool want[4] = {surface, surface, surface, surface && C.track_live};
+    const uint32_t mult[4] = {1u, 3u, 3u, 3u};
+    uint32_t *const ctr[4] = {&C.counters->n_rays[next_idx].v, &C.counters->n_paths[next_idx].v, &C.counters->n_free.v,
+                              &C.counters->live[q].v};  // three more unfinished paths of this pass
+    const bool sub[4] = {false, false, true, false};
+    uint32_t idx[4];
+    block_alloc<4>(sh, want, mult, ctr, sub, idx);
     if (!surface) return;
     const uint32_t ri = idx[0], pi = idx[1], fi = idx[2];
     next.ray_o[ri] = make_float4(pos.x, pos.y, pos.z, 0.f);
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
 #pragma unroll
     for (uint32_t c = 0; c < 3; ++c) {
         const uint32_t slot = C.free_slots[fi + c];
-        next.rec0[pi + c] = make_uint4(s * 3u + c, ri, kFresh, 0u);
+        next.rec0[pi + c] = make_uint4(s * 3u + c, ri, kFresh | (q ? kPassBit : 0u), 0u);
         next.rec1[pi + c] = make_float4(0.f, 0.f, 0.f, __uint_as_float(slot));
     }
 }
@@ -447,6 +451,7 @@ __global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Coun
         c->n_paths[0].v = c->n_paths[1].v = 0;
         c->n_rays[0].v = c->n_rays[1].v = 0;
         c->n_free.v = pool;
+        c->live[0].v = c->live[1].v = 0;
         c->n_shadow[0].v = c->n_shadow[1].v = 0;
         c->n_direct[0].v = c->n_direct[1].v = 0;
         c->pushes.v = 0;
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     const int next_idx = cur_idx ^ 1;
 
     uint32_t pid = 0, slot = 0, depth = 0, ray_idx = 0;
-    int ch = 0;
+    int ch = 0, pq = 0;  // pq: parity of the pass the path belongs to
     RngKey key{0, 0, 0, 0};
     bool do_shade = false, finished = false, pushed = false, overflow = false;
     float X = 0.f;
@@ -596,7 +601,8 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
         depth = r0.z & 0xffffu;
         const uint32_t flags = r0.z;
         slot = __float_as_uint(r1.w);
-        path_key(C, pid, key, ch);
+        pq = (int)((flags >> 20) & 1u);
+        path_key(C, pid, pq, key, ch);
 
         if (!(flags & kFresh)) {
             // ---- resolve the pending vertex: Scene.cpp:114-119 (l_dir), 129-149 / 156-176 (l_ind)
@@ -681,7 +687,7 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     // ---- finish: unwind the clamp stack and publish the path value
     if (finished) {
         X = unwind(C, slot, depth, X);
-        C.result[pid] = X;
+        (pq ? C.result[1] : C.result[0])[pid] = X;
     }
 
     // ---- shade the new vertex: Scene.cpp:109-128,150-155
@@ -702,13 +708,14 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     // one round of block-aggregated atomics: released slots, next-list records, continuation rays, the direct-
     // lighting work list, statistics.  The BSDF sampling below does not need the indices and runs while the
     // atomics are in flight.
-    const bool want[6] = {finished, do_shade, has_cont, need_direct, pushed, overflow};
-    const uint32_t mult[6] = {1u, 1u, 1u, 1u, 1u, 1u};
-    uint32_t *const ctr[6] = {&C.counters->n_free.v, &C.counters->n_paths[next_idx].v, &C.counters->n_rays[next_idx].v,
-                              &C.counters->n_direct[next_idx].v, &C.counters->pushes.v, &C.counters->overflow.v};
-    const bool sub[6] = {false, false, false, false, false, false};
-    uint32_t prefix[6], idx[6];
-    block_alloc_begin<6>(sh, want, mult, ctr, sub, prefix);
+    const bool want[8] = {finished, do_shade, has_cont, need_direct, pushed, overflow, finished && C.track_live && pq == 0, finished && C.track_live && pq == 1};
+    const uint32_t mult[8] = {1u, 1u, 1u, 1u, 1u, 1u, 1u, 1u};
+    uint32_t *const ctr[8] = {&C.counters->n_free.v, &C.counters->n_paths[next_idx].v, &C.counters->n_rays[next_idx].v,
+                              &C.counters->n_direct[next_idx].v, &C.counters->pushes.v, &C.counters->overflow.v,
+                              &C.counters->live[0].v, &C.counters->live[1].v};
+    const bool sub[8] = {false, false, false, false, false, false, true, true};
+    uint32_t prefix[8], idx[8];
+    block_alloc_begin<8>(sh, want, mult, ctr, sub, prefix);
 
     float kr = 0.f, ev = 0.f, aw = 0.f, pd = 0.f;
     f3 p2 = mk3(0, 0, 0), wi = mk3(0, 0, 1);
@@ -730,7 +737,7 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
         }
     }
 
-    block_alloc_end<6>(sh, mult, prefix, idx);
+    block_alloc_end<8>(sh, mult, prefix, idx);
     if (finished) C.free_slots[idx[0]] = slot;
     if (!do_shade) return;
     const uint32_t j = idx[1], rj = idx[2], dj = idx[3];
@@ -742,7 +749,7 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
                                                                     (zero_direct ? (1u << 19) : 0u)));
         Xs.vtx_j[dj] = j;
     }
-    uint32_t flags = depth | (inside ? kInside : 0u) | (need_direct ? 0u : kNoDirect);
+    uint32_t flags = depth | (inside ? kInside : 0u) | (need_direct ? 0u : kNoDirect) | (pq ? kPassBit : 0u);
     if (has_cont) {
         next.ray_o[rj] = make_float4(p2.x, p2.y, p2.z, 0.f);
         next.ray_d[rj] = make_float4(wi.x, wi.y, wi.z, 0.f);
@@ -785,7 +792,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wa
         const f2 uv{v0.w, v1.w};
         RngKey key;
         int ch;
-        path_key(C, r0.x, key, ch);
+        path_key(C, r0.x, (int)((r0.z >> 20) & 1u), key, ch);
         float u[4];
         rng_block(key, r0.z & 0xffffu, 1u + k, u);
         f3 x_l = mk3(0, 0, 0), n_l = mk3(0, 0, 0), emit3 = mk3(0, 0, 0);
@@ -864,14 +871,14 @@ void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, hipStrea
     hipLaunchKernelGGL(k_init_free, dim3(blocks(pool)), dim3(kBlock), 0, s, free_slots, c, pool);
 }
 
-void launch_primary(const DevScene &S, const CameraConst &cam, const RenderConst &C, Wave next, int next_idx,
+void launch_primary(const DevScene &S, const CameraConst &cam, const RenderConst &C, Wave next, int next_idx, int parity,
                     uint32_t first_sample, uint32_t n_samples, hipStream_t s) {
     if (n_samples == 0) return;
     const dim3 g(blocks(n_samples)), b(kBlock);
-    if (S.height <= 16) hipLaunchKernelGGL((k_primary<16>), g, b, 0, s, S, cam, C, next, next_idx, first_sample, n_samples);
-    else if (S.height <= 24) hipLaunchKernelGGL((k_primary<24>), g, b, 0, s, S, cam, C, next, next_idx, first_sample, n_samples);
-    else if (S.height <= 32) hipLaunchKernelGGL((k_primary<32>), g, b, 0, s, S, cam, C, next, next_idx, first_sample, n_samples);
-    else hipLaunchKernelGGL((k_primary<kMaxBvhHeight>), g, b, 0, s, S, cam, C, next, next_idx, first_sample, n_samples);
+    if (S.height <= 16) hipLaunchKernelGGL((k_primary<16>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
+    else if (S.height <= 24) hipLaunchKernelGGL((k_primary<24>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
+    else if (S.height <= 32) hipLaunchKernelGGL((k_primary<32>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
+    else hipLaunchKernelGGL((k_primary<kMaxBvhHeight>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
 }
 
 void launch_generate_explicit(const RenderConst &C, Wave next, int next_idx, uint32_t n, hipStream_t s) {
