@@ -9,14 +9,15 @@
 namespace mcpt {
 
 constexpr float kEps = 1e-4f;                 // EPSILON, reference Renderer.cpp:15
-constexpr int kNoChild = 0x7fffffff;          // absent child
+constexpr int kNoChild = 0x7fffffff;          // filler in placeholder records that are never traversed
 constexpr int kMaxBvhHeight = 48;             // traversal stack entries per lane (LDS)
 constexpr int kMaxLightTreeDepth = 64;
 
 // BVH2 node, 64 bytes = four 16-byte loads.  Both children's boxes live in the parent so that one
-// fetch decides both descents.  child >= 0: inner node index; child < 0: leaf, primitive id = ~child;
-// kNoChild: absent.  Topology mirrors the reference's two-level median-split trees (BVH.cpp:27-93)
-// flattened into one array: a scene-level leaf that is a mesh is replaced by the mesh's own root.
+// fetch decides both descents.  child >= 0: inner node index; child < 0: leaf, primitive id = ~child; every inner node
+// has two children.  Default tree: one binned-SAH BVH over all primitives; MCPT_BVH=reference keeps the reference's
+// two-level median-split topology (BVH.cpp:27-93) flattened into one array (a scene-level leaf that is a mesh is
+// replaced by the mesh's own root).
 struct alignas(16) Node {
     float lmin[3], lmax[3];
     float rmin[3], rmax[3];
@@ -101,7 +102,6 @@ struct HostScene {
     std::vector<Node> nodes;
     std::vector<TriGeom> tri_geom;
     std::vector<TriShade> tri_shade;
-    std::vector<float> tri_area;
     std::vector<SphereRec> spheres;       // indexed by object index (entries for meshes unused)
     std::vector<MaterialRec> materials;
     std::vector<LightRec> lights;

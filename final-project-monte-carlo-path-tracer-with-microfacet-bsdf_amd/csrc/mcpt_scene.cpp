@@ -290,7 +290,6 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) 
 
     hs.tri_geom.resize(d.n_triangles);
     hs.tri_shade.resize(d.n_triangles);
-    hs.tri_area.resize(d.n_triangles);
     hs.spheres.resize(d.n_objects);
     std::memset(hs.spheres.data(), 0, hs.spheres.size() * sizeof(SphereRec));
 
@@ -362,7 +361,6 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) 
                     s.t1[q] = t.t1[q];
                     s.t2[q] = t.t2[q];
                 }
-                hs.tri_area[ti] = a;
                 BObj &T = tri_objs[ti];
                 T.prim = ti;
                 T.bounds = box_union(box_pp(v0, v1), v2);  // Triangle::getBounds, Triangle.hpp:220

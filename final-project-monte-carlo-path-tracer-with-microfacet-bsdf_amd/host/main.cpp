@@ -15,13 +15,13 @@
 #include "Renderer.hpp"
 #include "json_min.hpp"
 
-static bool is_v3(const Json &d) {
+[[maybe_unused]] static bool is_v3(const Json &d) {
     if (!d.is_array() || d.size() != 3) return false;
     for (size_t i = 0; i < 3; ++i)
         if (!d[i].is_number()) return false;
     return true;
 }
-static Vector3f v3(const Json &d) { return Vector3f(d[0].as_float(), d[1].as_float(), d[2].as_float()); }
+[[maybe_unused]] static Vector3f v3(const Json &d) { return Vector3f(d[0].as_float(), d[1].as_float(), d[2].as_float()); }
 
 static Vector3f light_emission(float scale) {  // main.cpp:100-104,303-308
     return scale * (8.0f * Vector3f(0.747f + 0.058f, 0.747f + 0.258f, 0.747f) + 15.6f * Vector3f(0.740f + 0.287f, 0.740f + 0.160f, 0.740f) +
