@@ -849,17 +849,22 @@ inline uint32_t blocks(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 // In the regular schedule k_primary may already be appending fresh records to list `next` on another stream, so the host
 // passes the lengths it read right after k_shade (from_host); in the drain phase they are read here.
 __global__ void k_bookkeep(Counters *c, int cur_idx, int from_host, uint32_t n_next, uint32_t n_cont, uint32_t n_direct) {
-    if (threadIdx.x == 0) {
-        const int nxt = cur_idx ^ 1;
-        c->tot_shadow += c->n_shadow[cur_idx].v;
-        c->tot_shaded += from_host ? n_next : c->n_paths[nxt].v;
-        c->tot_cont += from_host ? n_cont : c->n_rays[nxt].v;
-        c->tot_direct += from_host ? n_direct : c->n_direct[nxt].v;
-        c->tot_iterations += 1;
-        c->n_paths[cur_idx].v = 0;
-        c->n_rays[cur_idx].v = 0;
-        c->n_direct[cur_idx].v = 0;
+    const int nxt = cur_idx ^ 1;
+    switch (threadIdx.x) {  // one lane per field: the global accesses are independent and overlap
+    case 0: {
+        const uint32_t v = c->n_shadow[cur_idx].v;
         c->n_shadow[cur_idx].v = 0;
+        c->tot_shadow += v;
+        break;
+    }
+    case 1: c->tot_shaded += from_host ? n_next : c->n_paths[nxt].v; break;
+    case 2: c->tot_cont += from_host ? n_cont : c->n_rays[nxt].v; break;
+    case 3: c->tot_direct += from_host ? n_direct : c->n_direct[nxt].v; break;
+    case 4: c->tot_iterations += 1; break;
+    case 5: c->n_paths[cur_idx].v = 0; break;
+    case 6: c->n_rays[cur_idx].v = 0; break;
+    case 7: c->n_direct[cur_idx].v = 0; break;
+    default: break;
     }
 }
 
