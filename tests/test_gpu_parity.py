@@ -217,3 +217,30 @@ def test_error_paths(pkg, hip):
     bad.objects["material"][0] = 99
     with pytest.raises(hip.McptError):
         hip.HipScene(bad)
+
+
+def test_full_size_properties(pkg, oracle, hip):
+    """BASELINE configs 3-5 at their real size (chess 1920x1080), through size-independent properties:
+    (a) the 8-rank interleaved-tile partition sums to the 1-rank frame bit for bit (disjoint pixels, same Philox keys);
+    (b) the library's reference-equivalent work counters equal the reference's measured call counts per sample
+        (SURVEY.md App. D: 8.80 scene rays, 3.28 castRay invocations per sample);
+    (c) the frame, box-filtered 8x8, agrees with an oracle render of the same scene at 240x135 (each oracle pixel
+        integrates the same 8x8 footprint), within Monte Carlo noise."""
+    sd = pkg.scenes.chess_scene(width=1920, height=1080, spp=4)
+    hs = hip.HipScene(sd)
+    full, st = hs.render(spp=4, seed=11)
+    acc = np.zeros_like(full)
+    for r in range(8):
+        part, _ = hs.render(spp=4, seed=11, tile_size=32, rank=r, nranks=8)
+        assert not ((part != 0) & (acc != 0)).any()
+        acc += part
+    assert np.array_equal(full, acc)
+    assert st.samples == 1920 * 1080 * 4
+    assert st.ref_scene_rays / st.samples == pytest.approx(8.80, rel=0.02)
+    assert st.vertices / st.samples == pytest.approx(3.28, rel=0.01)
+    small = pkg.scenes.chess_scene(width=240, height=135, spp=32)
+    ref, _ = oracle.OracleScene(small).render(spp=32, seed=5)
+    blocks = full.reshape(135, 8, 240, 8, 3).mean(axis=(1, 3))
+    a, b = np.clip(ref, 0, 2), np.clip(blocks, 0, 2)
+    assert np.abs(a.mean(axis=(0, 1)) - b.mean(axis=(0, 1))).max() < 0.01 * a.mean()
+    assert np.corrcoef(a.ravel(), b.ravel())[0, 1] > 0.95  # two oracle renders with different seeds correlate at 0.954
