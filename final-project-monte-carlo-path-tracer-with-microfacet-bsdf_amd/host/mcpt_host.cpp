@@ -9,7 +9,7 @@
 #include <sstream>
 #include <unordered_map>
 
-#include "Renderer.hpp"
+#include "mcpt_host.hpp"
 #include "png_min.hpp"
 
 // ------------------------------------------------------------------------------------------------ OBJ

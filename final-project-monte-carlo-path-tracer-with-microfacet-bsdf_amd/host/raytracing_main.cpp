@@ -12,7 +12,7 @@
 #include <sstream>
 #include <unordered_map>
 
-#include "Renderer.hpp"
+#include "mcpt_host.hpp"
 #include "json_min.hpp"
 
 [[maybe_unused]] static bool is_v3(const Json &d) {
