@@ -467,10 +467,10 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     HIP_TRY(hipStreamSynchronize(st));
     T.collect();
     const Counters &hc = *w.h_counters;
-    ctx.pushes += hc.pushes.v;
+    ctx.pushes += hc.tot_pushes + hc.pushes.v;
     ctx.overflow += hc.overflow.v;
     tot.iterations += hc.tot_iterations;
-    tot.shaded += hc.tot_shaded;
+    tot.shaded += hc.tot_shaded + hc.tot_ended + hc.ended.v;
     tot.direct += hc.tot_direct;
     tot.closest += hc.tot_cont;
     tot.shadow += hc.tot_shadow + hc.n_shadow[0].v + hc.n_shadow[1].v;

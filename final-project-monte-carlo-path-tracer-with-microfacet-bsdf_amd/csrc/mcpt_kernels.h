@@ -26,16 +26,18 @@ struct Counters {
     HotCounter n_direct[2]; // vertices that need direct lighting: length of the k_direct work list (same indexing)
     HotCounter n_free;      // entries in the free-slot stack
     HotCounter live[2];     // unfinished paths of the pass with that parity (a pass is complete when it reaches 0)
-    HotCounter pushes;      // cumulative: recursion levels entered (castRay depth+1 calls)
+    HotCounter pushes;      // recursion levels entered (castRay depth+1 calls); folded into tot_pushes by k_bookkeep
     HotCounter overflow;    // cumulative: paths cut by max_depth
+    HotCounter ended;       // vertices shaded and finished in the same k_shade call (no record); folded into tot_ended
     // cumulative totals kept on the device by k_bookkeep (the host does not see every iteration's counts)
-    unsigned long long tot_shaded, tot_direct, tot_shadow, tot_cont, tot_iterations;
+    unsigned long long tot_shaded, tot_direct, tot_shadow, tot_cont, tot_iterations, tot_pushes, tot_ended;
 };
 
 // One side of the double-buffered wavefront state (all SoA, 16-byte records, indexed by list position).
 struct Wave {
     uint4 *rec0;      // {pid, ray index, depth|flags, kr bits}
-    float4 *rec1;     // {eval, |wo.n| or -1 for Dirac, pdf, clamp-stack slot bits}
+    float4 *rec1;     // {eval, |wo.n| or -1 for Dirac, pdf, clamp-stack slot bits}; not written for kTerminate records,
+                      // which keep the slot in rec0.y (they have no ray)
     float4 *ray_o;    // closest-hit queue: origin
     float4 *ray_d;    // closest-hit queue: direction
     uint4 *hit;       // closest-hit results: {t lo, t hi, prim, 0}

@@ -36,7 +36,7 @@ MCPT_DI uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amd
 // workgroup (lane k of wave 0 adds the block total of request k), instead of one returning atomic per
 // wave and counter: the hot counters are the only cross-workgroup contention points of the pipeline.
 // Must be called by every thread of the block (it contains barriers).
-constexpr int kMaxAlloc = 8;
+constexpr int kMaxAlloc = 9;
 constexpr int kMaxWaves = 16;
 struct BlockAllocShared {
     uint32_t cnt[kMaxWaves][kMaxAlloc];
@@ -456,7 +456,8 @@ __global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Coun
         c->n_direct[0].v = c->n_direct[1].v = 0;
         c->pushes.v = 0;
         c->overflow.v = 0;
-        c->tot_shaded = c->tot_direct = c->tot_shadow = c->tot_cont = c->tot_iterations = 0;
+        c->ended.v = 0;
+        c->tot_shaded = c->tot_direct = c->tot_shadow = c->tot_cont = c->tot_iterations = c->tot_pushes = c->tot_ended = 0;
     }
 }
 
@@ -595,12 +596,17 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
 
     if (valid) {
         const uint4 r0 = cur.rec0[i];
-        const float4 r1 = cur.rec1[i];
-        pid = r0.x;
-        ray_idx = r0.y;
-        depth = r0.z & 0xffffu;
         const uint32_t flags = r0.z;
-        slot = __float_as_uint(r1.w);
+        float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        pid = r0.x;
+        depth = r0.z & 0xffffu;
+        if (flags & kTerminate) {  // no ray, no BSDF terms: the record is rec0 alone, with the slot where the ray index would be
+            slot = r0.y;
+        } else {
+            r1 = cur.rec1[i];
+            ray_idx = r0.y;
+            slot = __float_as_uint(r1.w);
+        }
         pq = (int)((flags >> 20) & 1u);
         path_key(C, pid, pq, key, ch);
 
@@ -708,14 +714,20 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     // one round of block-aggregated atomics: released slots, next-list records, continuation rays, the direct-
     // lighting work list, statistics.  The BSDF sampling below does not need the indices and runs while the
     // atomics are in flight.
-    const bool want[8] = {finished, do_shade, has_cont, need_direct, pushed, overflow, finished && C.track_live && pq == 0, finished && C.track_live && pq == 1};
-    const uint32_t mult[8] = {1u, 1u, 1u, 1u, 1u, 1u, 1u, 1u};
-    uint32_t *const ctr[8] = {&C.counters->n_free.v, &C.counters->n_paths[next_idx].v, &C.counters->n_rays[next_idx].v,
+    // A vertex where roulette ends the path and whose light samples all contribute zero returns l_dir = kr * 0
+    // (Scene.cpp:129-131,156-158) with nothing left to wait for: the path is finished here instead of leaving a
+    // record for the next iteration.
+    const bool ends_here = do_shade && !has_cont && !need_direct;
+    const bool done = finished || ends_here;
+    const bool want[9] = {done, do_shade && !ends_here, has_cont, need_direct, pushed, overflow, done && C.track_live && pq == 0,
+                          done && C.track_live && pq == 1, ends_here};
+    const uint32_t mult[9] = {1u, 1u, 1u, 1u, 1u, 1u, 1u, 1u, 1u};
+    uint32_t *const ctr[9] = {&C.counters->n_free.v, &C.counters->n_paths[next_idx].v, &C.counters->n_rays[next_idx].v,
                               &C.counters->n_direct[next_idx].v, &C.counters->pushes.v, &C.counters->overflow.v,
-                              &C.counters->live[0].v, &C.counters->live[1].v};
-    const bool sub[8] = {false, false, false, false, false, false, true, true};
-    uint32_t prefix[8], idx[8];
-    block_alloc_begin<8>(sh, want, mult, ctr, sub, prefix);
+                              &C.counters->live[0].v, &C.counters->live[1].v, &C.counters->ended.v};
+    const bool sub[9] = {false, false, false, false, false, false, true, true, false};
+    uint32_t prefix[9], idx[9];
+    block_alloc_begin<9>(sh, want, mult, ctr, sub, prefix);
 
     float kr = 0.f, ev = 0.f, aw = 0.f, pd = 0.f;
     f3 p2 = mk3(0, 0, 0), wi = mk3(0, 0, 1);
@@ -737,9 +749,14 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
         }
     }
 
-    block_alloc_end<8>(sh, mult, prefix, idx);
-    if (finished) C.free_slots[idx[0]] = slot;
+    block_alloc_end<9>(sh, mult, prefix, idx);
+    if (done) C.free_slots[idx[0]] = slot;
     if (!do_shade) return;
+    if (ends_here) {
+        const float l_dir = inside ? (float)((1. - (double)kr) * (double)0.f) : kr * 0.f;  // Scene.cpp:116-119 with l_dir == 0
+        (pq ? C.result[1] : C.result[0])[pid] = unwind(C, slot, depth, l_dir);
+        return;
+    }
     const uint32_t j = idx[1], rj = idx[2], dj = idx[3];
 
     if (need_direct) {  // work-list entry for k_direct (Scene::directLighting runs there, one lane per light sample)
@@ -756,8 +773,8 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     } else {
         flags |= kTerminate;
     }
-    next.rec0[j] = make_uint4(pid, rj, flags, __float_as_uint(kr));
-    next.rec1[j] = make_float4(ev, aw, pd, __uint_as_float(slot));
+    next.rec0[j] = make_uint4(pid, has_cont ? rj : slot, flags, __float_as_uint(kr));
+    if (has_cont) next.rec1[j] = make_float4(ev, aw, pd, __uint_as_float(slot));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -861,6 +878,18 @@ __global__ void k_bookkeep(Counters *c, int cur_idx, int from_host, uint32_t n_n
     case 2: c->tot_cont += from_host ? n_cont : c->n_rays[nxt].v; break;
     case 3: c->tot_direct += from_host ? n_direct : c->n_direct[nxt].v; break;
     case 4: c->tot_iterations += 1; break;
+    case 8: {  // only k_shade (same stream, already finished) writes these two
+        const uint32_t v = c->ended.v;
+        c->ended.v = 0;
+        c->tot_ended += v;
+        break;
+    }
+    case 9: {
+        const uint32_t v = c->pushes.v;
+        c->pushes.v = 0;
+        c->tot_pushes += v;
+        break;
+    }
     case 5: c->n_paths[cur_idx].v = 0; break;
     case 6: c->n_rays[cur_idx].v = 0; break;
     case 7: c->n_direct[cur_idx].v = 0; break;
