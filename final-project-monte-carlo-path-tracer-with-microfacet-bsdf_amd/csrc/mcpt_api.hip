@@ -403,7 +403,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
                 T.end(ev, K_DIRECT, st);
                 if (C.enable_shadow) {
                     ev = T.begin(st);
-                    launch_trace_shadow(sc->view, w.counters.p, nxt, n_cur_max * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
+                    launch_trace_shadow(sc->view, w.counters.p, nxt, n_cur_max * (uint32_t)n_dir, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
                     T.end(ev, K_SHADOW, st);
                 }
                 ev = T.begin(st);
@@ -449,7 +449,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             T.end(ev, K_DIRECT, st);
             if (C.enable_shadow) {
                 ev = T.begin(st);
-                launch_trace_shadow(sc->view, w.counters.p, nxt, n_direct * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
+                launch_trace_shadow(sc->view, w.counters.p, nxt, n_direct * (uint32_t)n_dir, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
                 T.end(ev, K_SHADOW, st);
             }
         }
@@ -473,7 +473,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     tot.shaded += hc.tot_shaded + hc.tot_ended + hc.ended.v;
     tot.direct += hc.tot_direct;
     tot.closest += hc.tot_cont;
-    tot.shadow += hc.tot_shadow + hc.n_shadow[0].v + hc.n_shadow[1].v;
+    tot.shadow += hc.tot_shadow + hc.n_shadow[0].v + hc.n_shadow[1].v + hc.n_shadow_w[0].v + hc.n_shadow_w[1].v;
     return MCPT_OK;
 }
 

@@ -93,7 +93,8 @@ struct alignas(16) LightTri {
     float v0[3], v1[3], v2[3];
     float n[3];
     float area;
-    int32_t pad[3];
+    int32_t prim;  // global primitive id of this triangle (k_direct tests the sampled triangle itself first)
+    int32_t pad[2];
 };
 static_assert(sizeof(LightTri) == 64, "LightTri must be 64 bytes");
 

@@ -29,6 +29,7 @@ struct Counters {
     HotCounter pushes;      // recursion levels entered (castRay depth+1 calls); folded into tot_pushes by k_bookkeep
     HotCounter overflow;    // cumulative: paths cut by max_depth
     HotCounter ended;       // vertices shaded and finished in the same k_shade call (no record); folded into tot_ended
+    HotCounter n_shadow_w[2]; // shadow rays that still need the window search; stored from the END of the queue arrays
     // cumulative totals kept on the device by k_bookkeep (the host does not see every iteration's counts)
     unsigned long long tot_shaded, tot_direct, tot_shadow, tot_cont, tot_iterations, tot_pushes, tot_ended;
 };
@@ -51,7 +52,9 @@ struct Scratch {
     float4 *vtx1;   // {n.xyz, uv.y}
     float4 *vtx2;   // {wo.xyz, bits: material | channel << 16 | inside << 18}
     uint32_t *vtx_j;  // index of the vertex's record in the next path list
-    float4 *shq_o;  // compacted shadow queue: {origin.xyz, bits: index into contrib}
+    float4 *shq_o;  // compacted shadow queue: {origin.xyz, bits: index into contrib}.  Rays whose light sample was found by
+                    // k_direct's own test of the sampled primitive fill it from the front (occluder search only), the
+                    // others from the back (window search first)
     float4 *shq_d;  // {direction.xyz, distance to the light sample}
 };
 
@@ -98,9 +101,10 @@ void launch_trace_closest(const DevScene &S, uint32_t n, const uint32_t *n_dev, 
 // Direct lighting (Scene::directLighting, Scene.cpp:56-82) for the n_vertices entries of the k_direct work list:
 // one lane per (vertex, light sample); fills next.contrib and appends the non-zero samples to the shadow queue.
 void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_max, hipStream_t s);
-// Shadow queue (length in counters->n_shadow, at most n_max): zeroes contrib[] of invisible samples.
-void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, Scratch X, float *contrib,
-                         hipStream_t s);
+// Shadow queue (lengths in counters->n_shadow / n_shadow_w, together at most n_max; arrays of `cap` entries): zeroes
+// contrib[] of invisible samples.
+void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, uint32_t cap, Scratch X,
+                         float *contrib, hipStream_t s);
 // Shades list `cur_idx` (at most n_cur_max records; the true count is read from the device counter) into the other list.
 void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, Scratch X, int cur_idx, uint32_t n_cur_max,
                   hipStream_t s);

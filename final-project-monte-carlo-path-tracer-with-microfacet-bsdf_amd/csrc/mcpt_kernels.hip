@@ -218,14 +218,27 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
     }
 }
 
+// Primitive test shared with the leaf branch of the loop (k_direct tests the sampled light primitive with it).
+MCPT_DI bool prim_hit(const DevScene &S, int32_t prim, const Ray &r, double &t) {
+    if (prim < S.n_tri) {
+        double u, v;
+        return tri_hit(S.tri_geom[prim], r, t, u, v);
+    }
+    float ts = 0.f;
+    const bool h = sphere_hit(S.spheres[prim - S.n_tri], r, ts);
+    t = (double)ts;
+    return h;
+}
+
+// found: shadow queries only -- the window search is already settled (k_direct found the sampled primitive in the window).
 template <bool SHADOW, int STK>
-MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid) {
+MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, bool found = false) {
     TraceState st;
     st.best_t = DBL_MAX;
     st.best_prim = -1;
     st.best_mat = 0;
     st.occluded = false;
-    st.found = false;
+    st.found = found;
 #ifdef MCPT_TRAVERSAL_STATS
     st.nv = st.nt = st.iters = 0;
 #endif
@@ -236,10 +249,10 @@ MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_
         // Scene.cpp:74-75: a light sample counts iff the CLOSEST hit lies within EPSILON of the light distance,
         // i.e. iff some hit lies in the window AND no hit lies at or below dist - EPSILON.
         if (plain) {
-            traverse_loop<kWindow, STK, true>(S, r, dist, stk, tid, st);
+            if (!found) traverse_loop<kWindow, STK, true>(S, r, dist, stk, tid, st);
             if (st.found && !st.occluded) traverse_loop<kOccluder, STK, true>(S, r, dist, stk, tid, st);
         } else {
-            traverse_loop<kWindow, STK, false>(S, r, dist, stk, tid, st);
+            if (!found) traverse_loop<kWindow, STK, false>(S, r, dist, stk, tid, st);
             if (st.found && !st.occluded) traverse_loop<kOccluder, STK, false>(S, r, dist, stk, tid, st);
         }
     } else if (plain) {
@@ -283,17 +296,22 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n
 }
 
 // Shadow queue consumer: a fixed grid strides over the queue, whose length is only known on the device.
+// Items [0, n_found) are the front of the arrays (light sample already found: occluder search only), the next n_window
+// items are read from the back (window search first), so that the long occluder searches fill whole waves.
 template <int STK>
-__global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Counters *__restrict__ counters, int next_idx,
+__global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Counters *__restrict__ counters, int next_idx, uint32_t cap,
                                                          const float4 *__restrict__ shq_o, const float4 *__restrict__ shq_d,
                                                          float *__restrict__ contrib) {
     __shared__ int32_t stk[STK][kBlock];
     const int tid = threadIdx.x;
-    const uint32_t n = counters->n_shadow[next_idx].v;
+    const uint32_t n_found = counters->n_shadow[next_idx].v;
+    const uint32_t n = n_found + counters->n_shadow_w[next_idx].v;
     for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += gridDim.x * kBlock) {
-        const float4 o = shq_o[i], d = shq_d[i];
+        const bool found = i < n_found;
+        const uint32_t e = found ? i : cap - 1u - (i - n_found);
+        const float4 o = shq_o[e], d = shq_d[e];
         const Ray r = make_ray(ld3(o), ld3(d));
-        const TraceResult tr = traverse<true, STK>(S, r, d.w, stk, tid);
+        const TraceResult tr = traverse<true, STK>(S, r, d.w, stk, tid, found);
         if (!tr.visible) contrib[__float_as_uint(o.w)] = 0.f;  // Scene.cpp:74-79: an invisible sample adds nothing
     }
 }
@@ -453,6 +471,7 @@ __global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Coun
         c->n_free.v = pool;
         c->live[0].v = c->live[1].v = 0;
         c->n_shadow[0].v = c->n_shadow[1].v = 0;
+        c->n_shadow_w[0].v = c->n_shadow_w[1].v = 0;
         c->n_direct[0].v = c->n_direct[1].v = 0;
         c->pushes.v = 0;
         c->overflow.v = 0;
@@ -466,7 +485,7 @@ __global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Coun
 // -> BVHAccel::Sample/getSample (BVH.cpp:118-135) -> Triangle::Sample (Triangle.hpp:71-76).
 // u = {light choice, triangle pick, x, y}.  Returns false when no light was selected.
 // ------------------------------------------------------------------------------------------------
-MCPT_DI bool sample_light(const DevScene &S, const float u[4], f3 &x_l, f3 &n_l, f3 &emit, float &pdf) {
+MCPT_DI bool sample_light(const DevScene &S, const float u[4], f3 &x_l, f3 &n_l, f3 &emit, float &pdf, int32_t &prim) {
     float area_sum = 0.f;
     for (int k = 0; k < S.n_lights; ++k) area_sum += S.lights[k].area;
     const float p = u[0] * area_sum;
@@ -493,6 +512,7 @@ MCPT_DI bool sample_light(const DevScene &S, const float u[4], f3 &x_l, f3 &n_l,
                 const f3 v0 = mk3(T.v0[0], T.v0[1], T.v0[2]), v1 = mk3(T.v1[0], T.v1[1], T.v1[2]), v2 = mk3(T.v2[0], T.v2[1], T.v2[2]);
                 x_l = (v0 * (1.0f - x) + v1 * (x * (1.0f - y))) + v2 * (x * y);
                 n_l = mk3(T.n[0], T.n[1], T.n[2]);
+                prim = T.prim;
                 pdf = 1.0f / T.area;   // Triangle.hpp:75
                 pdf *= T.area;         // BVH.cpp:121
                 pdf /= L.root_area;    // BVH.cpp:134
@@ -503,6 +523,7 @@ MCPT_DI bool sample_light(const DevScene &S, const float u[4], f3 &x_l, f3 &n_l,
                 const f3 dir = mk3(cosf(phi), sinf(phi) * cosf(theta), sinf(phi) * sinf(theta));
                 x_l = mk3(s.c[0], s.c[1], s.c[2]) + dir * s.radius;
                 n_l = dir;
+                prim = S.n_tri + L.root;
                 pdf = 1.0f / L.area;
                 emit = mk3(0.f, 0.f, 0.f);
             }
@@ -791,7 +812,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wa
     const uint32_t n_dir = (uint32_t)C.n_dir;
     const uint32_t n_vertices = C.counters->n_direct[next_idx].v;  // the grid is an upper bound
     const bool valid = g < n_vertices * n_dir;
-    bool cast = false;
+    bool cast = false, window = false;
     f3 q = mk3(0, 0, 0), ws = mk3(0, 0, 1);
     float dist = 0.f;
     uint32_t target = 0;
@@ -814,14 +835,32 @@ __global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wa
         rng_block(key, r0.z & 0xffffu, 1u + k, u);
         f3 x_l = mk3(0, 0, 0), n_l = mk3(0, 0, 0), emit3 = mk3(0, 0, 0);
         float pdf = 0.f, c = 0.f;
-        if (sample_light(S, u, x_l, n_l, emit3, pdf)) {
+        int32_t light_prim = -1;
+        if (sample_light(S, u, x_l, n_l, emit3, pdf, light_prim)) {
             const float emit = comp(emit3, ch);
             ws = normalized(x_l - q);
             dist = norm(x_l - q);
             c = emit * mat_eval(m, ws, wo, n, ch, uv, !inside) * (dot(ws, n)) * dot(-ws, n_l) / (dist * dist) / pdf / C.n_dir;
         }
-        next.contrib[target] = c;
         cast = C.enable_shadow && !(c == 0.f);
+        if (cast) {
+            // Scene.cpp:72-75: the sample counts iff the closest hit of the shadow ray lies within EPSILON of `dist`.  The
+            // ray is aimed at a point of primitive light_prim, so that primitive is tested here: a hit closer than
+            // dist - EPSILON settles the sample as invisible (no ray at all); a hit inside the window settles the window
+            // search, leaving only the occluder search to k_trace_shadow; otherwise the full query runs.
+            double t = 0;
+            window = true;
+            if (prim_hit(S, light_prim, make_ray(q, ws), t)) {
+                const double dd = t - (double)dist;
+                if (dd <= -(double)kEps) {
+                    c = 0.f;
+                    cast = false;
+                } else if (fabs(dd) < (double)kEps) {
+                    window = false;
+                }
+            }
+        }
+        next.contrib[target] = c;
 #ifdef MCPT_CHECK_DIRECT_SKIP
         if (((bits >> 19) & 1u) && S.dbg) {
             atomicAdd(&S.dbg[14], 1ull);
@@ -829,15 +868,16 @@ __global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wa
         }
 #endif
     }
-    const bool want[1] = {cast};
-    const uint32_t mult[1] = {1u};
-    uint32_t *const ctr[1] = {&C.counters->n_shadow[next_idx].v};
-    const bool sub[1] = {false};
-    uint32_t idx[1];
-    block_alloc<1>(sh, want, mult, ctr, sub, idx);
+    const bool want[2] = {cast && !window, cast && window};
+    const uint32_t mult[2] = {1u, 1u};
+    uint32_t *const ctr[2] = {&C.counters->n_shadow[next_idx].v, &C.counters->n_shadow_w[next_idx].v};
+    const bool sub[2] = {false, false};
+    uint32_t idx[2];
+    block_alloc<2>(sh, want, mult, ctr, sub, idx);
     if (cast) {
-        Xs.shq_o[idx[0]] = make_float4(q.x, q.y, q.z, __uint_as_float(target));
-        Xs.shq_d[idx[0]] = make_float4(ws.x, ws.y, ws.z, dist);
+        const uint32_t e = window ? (uint32_t)C.pool * (uint32_t)C.n_dir - 1u - idx[1] : idx[0];
+        Xs.shq_o[e] = make_float4(q.x, q.y, q.z, __uint_as_float(target));
+        Xs.shq_d[e] = make_float4(ws.x, ws.y, ws.z, dist);
     }
 }
 
@@ -869,8 +909,9 @@ __global__ void k_bookkeep(Counters *c, int cur_idx, int from_host, uint32_t n_n
     const int nxt = cur_idx ^ 1;
     switch (threadIdx.x) {  // one lane per field: the global accesses are independent and overlap
     case 0: {
-        const uint32_t v = c->n_shadow[cur_idx].v;
+        const uint32_t v = c->n_shadow[cur_idx].v + c->n_shadow_w[cur_idx].v;
         c->n_shadow[cur_idx].v = 0;
+        c->n_shadow_w[cur_idx].v = 0;
         c->tot_shadow += v;
         break;
     }
@@ -942,8 +983,8 @@ void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X
     hipLaunchKernelGGL(k_direct, dim3(blocks(n_vertices_max * (uint32_t)C.n_dir)), dim3(kBlock), 0, s, S, C, next, X, next_idx);
 }
 
-void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, Scratch X, float *contrib,
-                         hipStream_t s) {
+void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, uint32_t cap, Scratch X,
+                         float *contrib, hipStream_t s) {
     if (n_max == 0) return;
     // The queue length is only known on the device.  The grid covers the upper bound (capped at 1024 workgroups per
     // CU, far more than are resident, so the hardware balances uneven rays dynamically: a persistent 8-per-CU grid
@@ -952,10 +993,10 @@ void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_i
     const char *cap_env = std::getenv("MCPT_SHADOW_GRID_PER_CU");
     const uint32_t per_cu = cap_env ? (uint32_t)std::max(1, std::atoi(cap_env)) : 1024u;
     const dim3 g(std::min<uint32_t>(blocks(n_max), 256u * per_cu)), b(kBlock);
-    if (stk == 16) hipLaunchKernelGGL((k_trace_shadow<16>), g, b, 0, s, S, counters, next_idx, X.shq_o, X.shq_d, contrib);
-    else if (stk == 24) hipLaunchKernelGGL((k_trace_shadow<24>), g, b, 0, s, S, counters, next_idx, X.shq_o, X.shq_d, contrib);
-    else if (stk == 32) hipLaunchKernelGGL((k_trace_shadow<32>), g, b, 0, s, S, counters, next_idx, X.shq_o, X.shq_d, contrib);
-    else hipLaunchKernelGGL((k_trace_shadow<kMaxBvhHeight>), g, b, 0, s, S, counters, next_idx, X.shq_o, X.shq_d, contrib);
+    if (stk == 16) hipLaunchKernelGGL((k_trace_shadow<16>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
+    else if (stk == 24) hipLaunchKernelGGL((k_trace_shadow<24>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
+    else if (stk == 32) hipLaunchKernelGGL((k_trace_shadow<32>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
+    else hipLaunchKernelGGL((k_trace_shadow<kMaxBvhHeight>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
 }
 
 void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, Scratch X, int cur_idx, uint32_t n_cur_max,

@@ -235,6 +235,7 @@ struct Flattener {
                 T.v2[k] = d.triangles[ti].v2[k];
                 T.n[k] = hs.tri_shade[ti].n[k];
             }
+            T.prim = ti;
             T.area = n->area;  // leaf BVHBuildNode::area == Triangle::area (BVH.cpp:38)
             hs.light_tris.push_back(T);
             return ~(int32_t)(hs.light_tris.size() - 1);
