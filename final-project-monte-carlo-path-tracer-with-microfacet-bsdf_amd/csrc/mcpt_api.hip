@@ -76,7 +76,7 @@ struct WaveBufs {
 };
 
 struct Workspace {
-    uint32_t pool = 0;
+    uint32_t pool = 0, free_ring = 0, ray_cap = 0;
     int32_t n_dir = 0, max_depth = 0;
     WaveBufs wave[2];
     DevBuf<float4> vtx0, vtx1, vtx2, shq_o, shq_d;
@@ -187,6 +187,7 @@ struct mcpt_scene {
         // independent: they run on separate streams and are joined before the next k_shade.
         hipStream_t side[2] = {nullptr, nullptr};
         hipEvent_t join[2] = {nullptr, nullptr};
+        hipEvent_t book = nullptr;  // main -> primary stream: the previous iteration's k_bookkeep has cleared the list counters
         uint64_t pushes = 0, overflow = 0;
         int rc = 0;
         std::string err;
@@ -220,7 +221,11 @@ hipError_t ensure_workspace(PoolCtx &ctx, uint32_t pool, int32_t n_dir, int32_t 
     if ((e = w.shq_o.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
     if ((e = w.shq_d.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
     if ((e = w.stack.alloc((size_t)pool * max_depth)) != hipSuccess) return e;
-    if ((e = w.free_slots.alloc(pool)) != hipSuccess) return e;
+    uint32_t ring = 1;
+    while (ring < pool) ring <<= 1;  // free-slot ring: power of two, so that the 32-bit head/tail counters may wrap
+    if ((e = w.free_slots.alloc(ring)) != hipSuccess) return e;
+    w.free_ring = ring;
+    w.ray_cap = (uint32_t)n_rays;
     if ((e = w.counters.alloc(1)) != hipSuccess) return e;
     if (!w.h_counters && (e = hipHostMalloc((void **)&w.h_counters, sizeof(Counters))) != hipSuccess) return e;
     w.pool = pool;
@@ -304,16 +309,24 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     C.pool = w.pool;
     C.stack = w.stack.p;
     C.free_slots = w.free_slots.p;
+    C.free_mask = w.free_ring - 1u;
+    C.ray_cap = w.ray_cap;
     C.counters = w.counters.p;
     const uint32_t pool = w.pool;
     const int n_dir = C.n_dir;
     const int P = (int)plan.size();
     C.track_live = (acc && P > 1) ? 1 : 0;
     launch_init_free(w.free_slots.p, w.counters.p, pool, st);
+    if (ctx.side[1]) {  // fork: the side streams start after everything queued on `st` so far (counters, pixel list, framebuffer)
+        HIP_TRY(hipEventRecord(ctx.book, st));
+        for (int k = 0; k < 2; ++k) HIP_TRY(hipStreamWaitEvent(ctx.side[k], ctx.book, 0));
+    }
     int cur = 0;
     uint32_t n_cur_max = 0;  // upper bound of the record count of wave[cur] (the exact count lives on the device)
     int issue_pass = 0, accum_next = 0;
     uint32_t issued = 0;
+    uint32_t free_known = 0;  // free slots according to the last read-back (a lower bound of what k_primary may pop)
+    bool have_counters = false;  // w.h_counters holds a read-back of THIS call
     long it = 0;
     std::vector<long> issue_done_iter(P, -1);
     hipStream_t s_close = ctx.side[0] ? ctx.side[0] : st, s_prim = ctx.side[1] ? ctx.side[1] : st;
@@ -349,7 +362,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     };
     // accumulates, in order, every pass that is complete according to the counters just read back
     auto accumulate_done = [&](hipStream_t s) {
-        while (acc && accum_next < issue_pass && issue_done_iter[accum_next] < it &&
+        while (acc && have_counters && accum_next < issue_pass && issue_done_iter[accum_next] < it &&
                (C.track_live ? w.h_counters->live[accum_next & 1].v == 0 : (n_cur_max == 0 && issue_pass >= P))) {
             int ev = T.begin(s);
             launch_accumulate(acc->result[accum_next & 1], acc->pixel_list, acc->n_pix, plan[accum_next].s_pass, acc->spp_total, acc->fb, s);
@@ -414,6 +427,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             T.collect();
+        have_counters = true;
             n_cur_max = w.h_counters->n_paths[cur].v;
             accumulate_done(st);
             continue;
@@ -421,28 +435,41 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
         const int nxt = cur ^ 1;
         Wave cw = w.wave[cur].view(), nx = w.wave[nxt].view();
         // (the counters indexed `nxt` were cleared by the previous iteration's k_bookkeep, or by k_init_free)
+        // New samples are generated CONCURRENTLY with k_shade (memory-latency-bound; the primary kernel is issue-bound):
+        // both append to list `nxt`.  How many fit is decided from the previous read-back: k_shade only ever adds free
+        // slots and never lengthens the list, so the slots and the list room known then are still there.
+        accumulate_done(s_prim);  // frees the result half that the pass after next needs; ordered before its k_primary
+        if (C.mode == 0 && n_cur_max < pool && free_known >= 3u) {
+            if (ctx.side[1]) HIP_TRY(hipStreamWaitEvent(s_prim, ctx.book, 0));
+            issue(nx, nxt, std::min<uint32_t>((pool - n_cur_max) / 3, free_known / 3));
+        }
         int ev = -1;
         if (n_cur_max > 0) {
             ev = T.begin(st);
             launch_shade(sc->view, C, cw, nx, w.scratch(), cur, n_cur_max, st);
             T.end(ev, K_SHADE, st);
         }
+        if (ctx.side[1]) {  // the read-back waits for the new samples (and for a k_accumulate issued above) as well
+            HIP_TRY(hipEventRecord(ctx.join[1], s_prim));
+            HIP_TRY(hipStreamWaitEvent(st, ctx.join[1], 0));
+        }
         HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         T.collect();
+        have_counters = true;
+        const uint32_t n_fresh = 3u * w.h_counters->n_prays[nxt].v;  // records of the new samples (three per surface hit)
         const uint32_t n_next = w.h_counters->n_paths[nxt].v, n_cont = w.h_counters->n_rays[nxt].v;
-        const uint32_t n_free = w.h_counters->n_free.v, n_direct = w.h_counters->n_direct[nxt].v;
+        const uint32_t n_direct = w.h_counters->n_direct[nxt].v;
+        free_known = w.h_counters->free_tail.v - w.h_counters->free_head.v;
 
-        // fork: everything below only depends on k_shade, which has completed (the host just synchronised on it)
+        // fork: everything below only depends on kernels that have completed (the host just synchronised on them)
         if (n_cont > 0) {
             ev = T.begin(s_close);
             launch_trace_closest(sc->view, n_cont, nullptr, nx.ray_o, nx.ray_d, nx.hit, s_close);
             T.end(ev, K_CLOSEST, s_close);
         }
-        accumulate_done(s_prim);  // frees the result half that the pass after next needs; ordered before its k_primary
-        uint32_t g = 0;
-        if (C.mode == 0) g = issue(nx, nxt, std::min<uint32_t>((pool - n_next) / 3, n_free / 3));
-        launch_bookkeep(w.counters.p, cur, true, n_next, n_cont, n_direct, st);  // totals += lengths; list `cur` is consumed
+        launch_bookkeep(w.counters.p, cur, true, n_next - n_fresh, n_cont, n_direct, st);  // totals += lengths; list `cur` is consumed
+        if (ctx.side[1]) HIP_TRY(hipEventRecord(ctx.book, st));
         if (n_direct > 0) {
             ev = T.begin(st);
             launch_direct(sc->view, C, nx, w.scratch(), nxt, n_direct, st);
@@ -454,12 +481,11 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             }
         }
         // join
-        for (int k = 0; k < 2; ++k) {
-            if (!ctx.side[k]) continue;
-            HIP_TRY(hipEventRecord(ctx.join[k], ctx.side[k]));
-            HIP_TRY(hipStreamWaitEvent(st, ctx.join[k], 0));
+        if (ctx.side[0]) {
+            HIP_TRY(hipEventRecord(ctx.join[0], ctx.side[0]));
+            HIP_TRY(hipStreamWaitEvent(st, ctx.join[0], 0));
         }
-        n_cur_max = n_next + 3 * g;
+        n_cur_max = n_next;
         cur = nxt;
     }
     // the last shadow queue was consumed after the last k_bookkeep: fold it into the totals
@@ -686,6 +712,7 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
                 e = hipStreamCreateWithFlags(&c.side[k], hipStreamNonBlocking);
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&c.join[k], hipEventDisableTiming);
             }
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c.book, hipEventDisableTiming);
         }
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->fork, hipEventDisableTiming);
@@ -770,6 +797,7 @@ void mcpt_scene_destroy(mcpt_scene *sc) {
         c.timer.release();
         for (int k = 0; k < 2; ++k) {
             if (c.join[k]) (void)hipEventDestroy(c.join[k]);
+            if (k == 0 && c.book) (void)hipEventDestroy(c.book);
             if (c.side[k]) (void)hipStreamDestroy(c.side[k]);
         }
         if (c.main) (void)hipStreamDestroy(c.main);

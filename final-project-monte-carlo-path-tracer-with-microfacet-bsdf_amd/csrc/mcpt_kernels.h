@@ -24,7 +24,11 @@ struct Counters {
     HotCounter n_rays[2];   // entries in closest-hit queue 0 / 1
     HotCounter n_shadow[2]; // entries in the shadow-ray queue (indexed like the list the rays belong to)
     HotCounter n_direct[2]; // vertices that need direct lighting: length of the k_direct work list (same indexing)
-    HotCounter n_free;      // entries in the free-slot stack
+    // Free clamp-stack slots: a ring of a power-of-two number of entries.  k_primary pops at `free_head`, k_shade pushes at
+    // `free_tail` (both only ever increase; entry = counter & mask), so the two kernels can run concurrently: the host only
+    // lets k_primary pop entries that were pushed by kernels which have already completed.
+    HotCounter free_head, free_tail;
+    HotCounter n_prays[2];  // primary rays of list 0 / 1: stored from the END of the ray arrays (they are already traced)
     HotCounter live[2];     // unfinished paths of the pass with that parity (a pass is complete when it reaches 0)
     HotCounter pushes;      // recursion levels entered (castRay depth+1 calls); folded into tot_pushes by k_bookkeep
     HotCounter overflow;    // cumulative: paths cut by max_depth
@@ -73,6 +77,8 @@ struct RenderConst {
     float4 *stack;  // [level][slot] = {clamp(0,15,l_dir), eval, |wo.n| or -1, pdf}
     float *result[2];  // per pass parity, per pid: castRay(ray, 0, channel)
     uint32_t *free_slots;
+    uint32_t free_mask;  // ring size - 1
+    uint32_t ray_cap;    // entries of the ray / hit arrays
     Counters *counters;
 };
 

@@ -421,19 +421,21 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
     }
     const bool want[4] = {surface, surface, surface, surface && C.track_live};
     const uint32_t mult[4] = {1u, 3u, 3u, 3u};
-    uint32_t *const ctr[4] = {&C.counters->n_rays[next_idx].v, &C.counters->n_paths[next_idx].v, &C.counters->n_free.v,
+    uint32_t *const ctr[4] = {&C.counters->n_prays[next_idx].v, &C.counters->n_paths[next_idx].v, &C.counters->free_head.v,
                               &C.counters->live[q].v};  // three more unfinished paths of this pass
-    const bool sub[4] = {false, false, true, false};
+    const bool sub[4] = {false, false, false, false};
     uint32_t idx[4];
     block_alloc<4>(sh, want, mult, ctr, sub, idx);
     if (!surface) return;
-    const uint32_t ri = idx[0], pi = idx[1], fi = idx[2];
+    // the ray is already traced: it goes to the back of the ray arrays, away from the continuation rays that a concurrent
+    // k_shade appends at the front for k_trace_closest
+    const uint32_t ri = C.ray_cap - 1u - idx[0], pi = idx[1], fi = idx[2];
     next.ray_o[ri] = make_float4(pos.x, pos.y, pos.z, 0.f);
     next.ray_d[ri] = make_float4(dir.x, dir.y, dir.z, 0.f);
     next.hit[ri] = pack_hit(tr.t, tr.prim, tr.mat_bits);
 #pragma unroll
     for (uint32_t c = 0; c < 3; ++c) {
-        const uint32_t slot = C.free_slots[fi + c];
+        const uint32_t slot = C.free_slots[(fi + c) & C.free_mask];
         next.rec0[pi + c] = make_uint4(s * 3u + c, ri, kFresh | (q ? kPassBit : 0u), 0u);
         next.rec1[pi + c] = make_float4(0.f, 0.f, 0.f, __uint_as_float(slot));
     }
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void k_generate_explicit(Wave next, Counter
     if (j == 0) {
         c->n_paths[next_idx].v = n;
         c->n_rays[next_idx].v = n;
-        c->n_free.v = 0;
+        c->free_head.v = n;  // slots 0 .. n-1 are taken (record j owns slot j)
     }
     if (j >= n) return;
     next.rec0[j] = make_uint4(j, j, kFresh, 0u);
@@ -468,7 +470,9 @@ __global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Coun
     if (j == 0) {
         c->n_paths[0].v = c->n_paths[1].v = 0;
         c->n_rays[0].v = c->n_rays[1].v = 0;
-        c->n_free.v = pool;
+        c->free_head.v = 0;
+        c->free_tail.v = pool;
+        c->n_prays[0].v = c->n_prays[1].v = 0;
         c->live[0].v = c->live[1].v = 0;
         c->n_shadow[0].v = c->n_shadow[1].v = 0;
         c->n_shadow_w[0].v = c->n_shadow_w[1].v = 0;
@@ -743,7 +747,7 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     const bool want[9] = {done, do_shade && !ends_here, has_cont, need_direct, pushed, overflow, done && C.track_live && pq == 0,
                           done && C.track_live && pq == 1, ends_here};
     const uint32_t mult[9] = {1u, 1u, 1u, 1u, 1u, 1u, 1u, 1u, 1u};
-    uint32_t *const ctr[9] = {&C.counters->n_free.v, &C.counters->n_paths[next_idx].v, &C.counters->n_rays[next_idx].v,
+    uint32_t *const ctr[9] = {&C.counters->free_tail.v, &C.counters->n_paths[next_idx].v, &C.counters->n_rays[next_idx].v,
                               &C.counters->n_direct[next_idx].v, &C.counters->pushes.v, &C.counters->overflow.v,
                               &C.counters->live[0].v, &C.counters->live[1].v, &C.counters->ended.v};
     const bool sub[9] = {false, false, false, false, false, false, true, true, false};
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     }
 
     block_alloc_end<9>(sh, mult, prefix, idx);
-    if (done) C.free_slots[idx[0]] = slot;
+    if (done) C.free_slots[idx[0] & C.free_mask] = slot;
     if (!do_shade) return;
     if (ends_here) {
         const float l_dir = inside ? (float)((1. - (double)kr) * (double)0.f) : kr * 0.f;  // Scene.cpp:116-119 with l_dir == 0
@@ -915,7 +919,7 @@ __global__ void k_bookkeep(Counters *c, int cur_idx, int from_host, uint32_t n_n
         c->tot_shadow += v;
         break;
     }
-    case 1: c->tot_shaded += from_host ? n_next : c->n_paths[nxt].v; break;
+    case 1: c->tot_shaded += from_host ? n_next : c->n_paths[nxt].v - 3u * c->n_prays[nxt].v; break;  // fresh records are not shaded vertices
     case 2: c->tot_cont += from_host ? n_cont : c->n_rays[nxt].v; break;
     case 3: c->tot_direct += from_host ? n_direct : c->n_direct[nxt].v; break;
     case 4: c->tot_iterations += 1; break;
@@ -933,6 +937,7 @@ __global__ void k_bookkeep(Counters *c, int cur_idx, int from_host, uint32_t n_n
     }
     case 5: c->n_paths[cur_idx].v = 0; break;
     case 6: c->n_rays[cur_idx].v = 0; break;
+    case 10: c->n_prays[cur_idx].v = 0; break;
     case 7: c->n_direct[cur_idx].v = 0; break;
     default: break;
     }
