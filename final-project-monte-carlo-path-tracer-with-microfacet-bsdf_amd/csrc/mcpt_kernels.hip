@@ -956,6 +956,7 @@ void launch_primary(const DevScene &S, const CameraConst &cam, const RenderConst
     if (n_samples == 0) return;
     const dim3 g(blocks(n_samples)), b(kBlock);
     if (S.height <= 16) hipLaunchKernelGGL((k_primary<16>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
+    else if (S.height <= 20) hipLaunchKernelGGL((k_primary<20>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
     else if (S.height <= 24) hipLaunchKernelGGL((k_primary<24>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
     else if (S.height <= 32) hipLaunchKernelGGL((k_primary<32>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
     else hipLaunchKernelGGL((k_primary<kMaxBvhHeight>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
@@ -978,6 +979,7 @@ void launch_trace_closest(const DevScene &S, uint32_t n, const uint32_t *n_dev, 
     if (n == 0) return;
     const dim3 g(blocks(n)), b(kBlock);
     if (S.height <= 16) hipLaunchKernelGGL((k_trace_closest<16>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
+    else if (S.height <= 20) hipLaunchKernelGGL((k_trace_closest<20>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
     else if (S.height <= 24) hipLaunchKernelGGL((k_trace_closest<24>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
     else if (S.height <= 32) hipLaunchKernelGGL((k_trace_closest<32>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
     else hipLaunchKernelGGL((k_trace_closest<kMaxBvhHeight>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
@@ -994,11 +996,12 @@ void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_i
     // The queue length is only known on the device.  The grid covers the upper bound (capped at 1024 workgroups per
     // CU, far more than are resident, so the hardware balances uneven rays dynamically: a persistent 8-per-CU grid
     // was 30 % slower on the Cornell box); workgroups past the end of the queue exit at once, longer queues stride.
-    const int stk = S.height <= 16 ? 16 : (S.height <= 24 ? 24 : (S.height <= 32 ? 32 : kMaxBvhHeight));
+    const int stk = S.height <= 16 ? 16 : (S.height <= 20 ? 20 : (S.height <= 24 ? 24 : (S.height <= 32 ? 32 : kMaxBvhHeight)));
     const char *cap_env = std::getenv("MCPT_SHADOW_GRID_PER_CU");
     const uint32_t per_cu = cap_env ? (uint32_t)std::max(1, std::atoi(cap_env)) : 1024u;
     const dim3 g(std::min<uint32_t>(blocks(n_max), 256u * per_cu)), b(kBlock);
     if (stk == 16) hipLaunchKernelGGL((k_trace_shadow<16>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
+    else if (stk == 20) hipLaunchKernelGGL((k_trace_shadow<20>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
     else if (stk == 24) hipLaunchKernelGGL((k_trace_shadow<24>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
     else if (stk == 32) hipLaunchKernelGGL((k_trace_shadow<32>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
     else hipLaunchKernelGGL((k_trace_shadow<kMaxBvhHeight>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);

@@ -1,8 +1,8 @@
 #!/bin/bash
-# A/B bench of two library builds on one box: tools/ab.sh LIB_A LIB_B [extra bench args]; alternates A,B,A,B.
-A=$1; B=$2; shift 2
+# A/B bench of library builds on one box: tools/ab.sh LIB_A LIB_B [LIB_C ...] [-- extra bench args]; round-robin, twice.
+LIBS=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do LIBS+=("$1"); shift; done; [ "$1" = "--" ] && shift
 for i in 1 2; do
-  for L in "$A" "$B"; do
+  for L in "${LIBS[@]}"; do
     MCPT_LIB=$L timeout -k 10 200 python bench.py --no-cpu-baseline --no-psnr "$@" > gpurun_out/ab_tmp.log 2>&1 || { tail -5 gpurun_out/ab_tmp.log; exit 1; }
     python - "$L" <<'PY'
 import json,sys

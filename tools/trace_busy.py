@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """Reads a rocprofv3 kernel-trace CSV and reports how busy the GPU was: wall span of the traced kernels, the union
 of their intervals (time with at least one kernel running), the idle gaps, and per-kernel summed / exclusive time."""
-import csv, sys, collections
+import csv, re, sys, collections
+
+def short(name):
+    m = re.search(r"(k_\w+?)(?:IL[ij](\d+)E)?(?:<|\(|E|$)", name)
+    if m:
+        return m.group(1)
+    return name[:40]
+
 
 def main(path, skip_frac=0.0):
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:60]))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
     rows.sort()
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     lo = t0 + (t1 - t0) * skip_frac
