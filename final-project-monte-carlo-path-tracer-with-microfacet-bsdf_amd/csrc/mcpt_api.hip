@@ -5,6 +5,7 @@
 // pool with new camera samples ("path regeneration") and traces all rays of the iteration in two launches
 // (closest-hit queue, shadow queue), so the GPU always works on full, compacted queues.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -111,25 +112,28 @@ struct SharedBufs {
 enum KClass { K_CLOSEST = 0, K_SHADOW, K_SHADE, K_GENERATE, K_RESOLVE, K_DIRECT, K_NCLASS };
 
 struct Timer {
+    // Two banks of events: the host runs one iteration ahead of the GPU, so the events of iteration i are only known to be
+    // complete once the read-back of iteration i+1 has arrived; iteration i+1 meanwhile records into the other bank.
     bool enabled = true;
-    std::vector<hipEvent_t> pool;
+    int bank = 0;
+    std::vector<hipEvent_t> pool[2];
     struct Rec { int a, b, cls; };
-    std::vector<Rec> recs;
-    size_t used = 0;
+    std::vector<Rec> recs[2];
+    size_t used[2] = {0, 0};
     double ms[K_NCLASS] = {0, 0, 0, 0, 0, 0};
     uint64_t count[K_NCLASS] = {0, 0, 0, 0, 0, 0};
     int get() {
-        if (used == pool.size()) {
+        if (used[bank] == pool[bank].size()) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return -1;
-            pool.push_back(e);
+            pool[bank].push_back(e);
         }
-        return (int)used++;
+        return (int)used[bank]++;
     }
     int begin(hipStream_t s) {
         if (!enabled) return -1;
         const int a = get();
-        if (a >= 0) (void)hipEventRecord(pool[a], s);
+        if (a >= 0) (void)hipEventRecord(pool[bank][a], s);
         return a;
     }
     void end(int a, int cls, hipStream_t s) {
@@ -137,25 +141,31 @@ struct Timer {
         if (!enabled || a < 0) return;
         const int b = get();
         if (b < 0) return;
-        (void)hipEventRecord(pool[b], s);
-        recs.push_back({a, b, cls});
+        (void)hipEventRecord(pool[bank][b], s);
+        recs[bank].push_back({a, b, cls});
     }
-    void collect() {  // call after a stream sync
-        for (const Rec &r : recs) {
+    void collect_bank(int k) {  // every event of bank k must have completed
+        for (const Rec &r : recs[k]) {
             float t = 0.f;
-            if (hipEventElapsedTime(&t, pool[r.a], pool[r.b]) == hipSuccess) ms[r.cls] += t;
+            if (hipEventElapsedTime(&t, pool[k][r.a], pool[k][r.b]) == hipSuccess) ms[r.cls] += t;
         }
-        recs.clear();
-        used = 0;
+        recs[k].clear();
+        used[k] = 0;
+    }
+    void collect() {  // call after a full stream sync
+        collect_bank(0);
+        collect_bank(1);
     }
     void reset() {
         for (int i = 0; i < K_NCLASS; ++i) { ms[i] = 0; count[i] = 0; }
-        recs.clear();
-        used = 0;
+        for (int k = 0; k < 2; ++k) { recs[k].clear(); used[k] = 0; }
+        bank = 0;
     }
     void release() {
-        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
-        pool.clear();
+        for (int k = 0; k < 2; ++k) {
+            for (hipEvent_t e : pool[k]) (void)hipEventDestroy(e);
+            pool[k].clear();
+        }
     }
 };
 
@@ -188,6 +198,7 @@ struct mcpt_scene {
         hipStream_t side[2] = {nullptr, nullptr};
         hipEvent_t join[2] = {nullptr, nullptr};
         hipEvent_t book = nullptr;  // main -> primary stream: the previous iteration's k_bookkeep has cleared the list counters
+        hipEvent_t shaded = nullptr, readback = nullptr;  // k_shade done (-> closest stream); counters are in host memory
         uint64_t pushes = 0, overflow = 0;
         int rc = 0;
         std::string err;
@@ -327,6 +338,9 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     uint32_t issued = 0;
     uint32_t free_known = 0;  // free slots according to the last read-back (a lower bound of what k_primary may pop)
     bool have_counters = false;  // w.h_counters holds a read-back of THIS call
+    // continuation rays / direct-lighting vertices per record, as observed in the last iteration: they size the grids of the
+    // kernels that are queued before the host knows the true lengths (grid-stride kernels: any grid is correct)
+    double cont_ratio = 1.0, direct_ratio = 1.0;
     long it = 0;
     std::vector<long> issue_done_iter(P, -1);
     hipStream_t s_close = ctx.side[0] ? ctx.side[0] : st, s_prim = ctx.side[1] ? ctx.side[1] : st;
@@ -394,6 +408,9 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
         }
     }
 
+    const char *qa = std::getenv("MCPT_QUEUE_AHEAD"), *hd = std::getenv("MCPT_HOST_DELAY_US");
+    const bool queue_ahead = !(qa && qa[0] == '0');
+    const int host_delay_us = hd ? std::atoi(hd) : 0;
     const char *db = std::getenv("MCPT_DRAIN_BATCH");  // iterations queued per host sync once no samples are left to issue
     const int drain_batch = db ? std::max(1, std::atoi(db)) : 4;
     while (n_cur_max > 0 || issue_pass < P || (acc && accum_next < P)) {
@@ -449,34 +466,49 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             launch_shade(sc->view, C, cw, nx, w.scratch(), cur, n_cur_max, st);
             T.end(ev, K_SHADE, st);
         }
+        if (ctx.side[0]) HIP_TRY(hipEventRecord(ctx.shaded, st));
         if (ctx.side[1]) {  // the read-back waits for the new samples (and for a k_accumulate issued above) as well
             HIP_TRY(hipEventRecord(ctx.join[1], s_prim));
             HIP_TRY(hipStreamWaitEvent(st, ctx.join[1], 0));
         }
         HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        T.collect();
-        have_counters = true;
-        const uint32_t n_fresh = 3u * w.h_counters->n_prays[nxt].v;  // records of the new samples (three per surface hit)
-        const uint32_t n_next = w.h_counters->n_paths[nxt].v, n_cont = w.h_counters->n_rays[nxt].v;
-        const uint32_t n_direct = w.h_counters->n_direct[nxt].v;
-        free_known = w.h_counters->free_tail.v - w.h_counters->free_head.v;
+        HIP_TRY(hipEventRecord(ctx.readback, st));
 
-        // fork: everything below only depends on kernels that have completed (the host just synchronised on them)
-        if (n_cont > 0) {
+        // queue_ahead: the rest of the iteration is queued BEFORE the host looks at the counters.  Every kernel reads the
+        // true queue lengths on the device and strides over its queue, so the grids only need estimates (the ratios seen in
+        // the previous iteration).  The GPU then never waits for the host round trip: while the host sizes the next
+        // iteration, the three chains below are running.  Otherwise the host waits first and launches exact grids.
+        uint32_t n_cont = 0, n_direct = 0;
+        auto wait_counters = [&]() -> int {
+            HIP_TRY(hipEventSynchronize(ctx.readback));
+            if (host_delay_us > 0) usleep((useconds_t)host_delay_us);  // test hook: a slow host
+            T.collect_bank(T.bank ^ 1);  // the previous iteration's kernels all finished before this iteration's k_shade
+            have_counters = true;
+            n_cont = w.h_counters->n_rays[nxt].v;
+            n_direct = w.h_counters->n_direct[nxt].v;
+            return MCPT_OK;
+        };
+        if (!queue_ahead) {
+            const int rc = wait_counters();
+            if (rc != MCPT_OK) return rc;
+        }
+        const uint32_t grid_cont = !queue_ahead ? n_cont : std::min<uint32_t>(n_cur_max, (uint32_t)(1.15 * cont_ratio * n_cur_max) + 4096u);
+        const uint32_t grid_direct = !queue_ahead ? n_direct : std::min<uint32_t>(n_cur_max, (uint32_t)(1.15 * direct_ratio * n_cur_max) + 4096u);
+        if (grid_cont > 0) {
+            if (ctx.side[0]) HIP_TRY(hipStreamWaitEvent(s_close, ctx.shaded, 0));
             ev = T.begin(s_close);
-            launch_trace_closest(sc->view, n_cont, nullptr, nx.ray_o, nx.ray_d, nx.hit, s_close);
+            launch_trace_closest(sc->view, grid_cont, queue_ahead ? &w.counters.p->n_rays[nxt].v : nullptr, nx.ray_o, nx.ray_d, nx.hit, s_close);
             T.end(ev, K_CLOSEST, s_close);
         }
-        launch_bookkeep(w.counters.p, cur, true, n_next - n_fresh, n_cont, n_direct, st);  // totals += lengths; list `cur` is consumed
+        launch_bookkeep(w.counters.p, cur, false, 0, 0, 0, st);  // totals += lengths; list `cur` is consumed
         if (ctx.side[1]) HIP_TRY(hipEventRecord(ctx.book, st));
-        if (n_direct > 0) {
+        if (grid_direct > 0) {
             ev = T.begin(st);
-            launch_direct(sc->view, C, nx, w.scratch(), nxt, n_direct, st);
+            launch_direct(sc->view, C, nx, w.scratch(), nxt, grid_direct, st);
             T.end(ev, K_DIRECT, st);
             if (C.enable_shadow) {
                 ev = T.begin(st);
-                launch_trace_shadow(sc->view, w.counters.p, nxt, n_direct * (uint32_t)n_dir, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
+                launch_trace_shadow(sc->view, w.counters.p, nxt, grid_direct * (uint32_t)n_dir, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
                 T.end(ev, K_SHADOW, st);
             }
         }
@@ -484,6 +516,17 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
         if (ctx.side[0]) {
             HIP_TRY(hipEventRecord(ctx.join[0], ctx.side[0]));
             HIP_TRY(hipStreamWaitEvent(st, ctx.join[0], 0));
+        }
+        if (queue_ahead) {
+            const int rc = wait_counters();
+            if (rc != MCPT_OK) return rc;
+        }
+        T.bank ^= 1;
+        const uint32_t n_next = w.h_counters->n_paths[nxt].v;  // shaded + fresh records
+        free_known = w.h_counters->free_tail.v - w.h_counters->free_head.v;
+        if (n_cur_max > 0) {
+            cont_ratio = (double)n_cont / n_cur_max;
+            direct_ratio = (double)n_direct / n_cur_max;
         }
         n_cur_max = n_next;
         cur = nxt;
@@ -713,8 +756,10 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&c.join[k], hipEventDisableTiming);
             }
             if (e == hipSuccess) e = hipEventCreateWithFlags(&c.book, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c.shaded, hipEventDisableTiming);
         }
     }
+    for (int q = 0; q < sc->n_pools && e == hipSuccess; ++q) e = hipEventCreateWithFlags(&sc->pools[q].readback, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->fork, hipEventDisableTiming);
     auto up = [&](auto &buf, const auto &vec) {
         if (e == hipSuccess) e = upload(buf, vec);
@@ -798,6 +843,8 @@ void mcpt_scene_destroy(mcpt_scene *sc) {
         for (int k = 0; k < 2; ++k) {
             if (c.join[k]) (void)hipEventDestroy(c.join[k]);
             if (k == 0 && c.book) (void)hipEventDestroy(c.book);
+            if (k == 0 && c.shaded) (void)hipEventDestroy(c.shaded);
+            if (k == 0 && c.readback) (void)hipEventDestroy(c.readback);
             if (c.side[k]) (void)hipStreamDestroy(c.side[k]);
         }
         if (c.main) (void)hipStreamDestroy(c.main);

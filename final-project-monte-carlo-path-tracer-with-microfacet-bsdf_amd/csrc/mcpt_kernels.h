@@ -101,12 +101,13 @@ void launch_primary(const DevScene &S, const CameraConst &cam, const RenderConst
 void launch_generate_explicit(const RenderConst &C, Wave next, int next_idx, uint32_t n, hipStream_t s);
 void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const uint32_t *pixel, const uint32_t *sample,
                         float4 *o, float4 *d, hipStream_t s);
-// n_dev != nullptr: the ray count is read on the device (n is then only the grid's upper bound).
+// n_dev != nullptr: the ray count is read on the device (n then only sizes the grid, which strides over the queue).
 void launch_trace_closest(const DevScene &S, uint32_t n, const uint32_t *n_dev, const float4 *ray_o, const float4 *ray_d, uint4 *hit,
                           hipStream_t s);
 // Direct lighting (Scene::directLighting, Scene.cpp:56-82) for the n_vertices entries of the k_direct work list:
-// one lane per (vertex, light sample); fills next.contrib and appends the non-zero samples to the shadow queue.
-void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_max, hipStream_t s);
+// one lane per (vertex, light sample); fills next.contrib and appends the non-zero samples to the shadow queue.  The list
+// length is read on the device; the grid (n_vertices_grid vertices) strides over it.
+void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_grid, hipStream_t s);
 // Shadow queue (lengths in counters->n_shadow / n_shadow_w, together at most n_max; arrays of `cap` entries): zeroes
 // contrib[] of invisible samples.
 void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, uint32_t cap, Scratch X,

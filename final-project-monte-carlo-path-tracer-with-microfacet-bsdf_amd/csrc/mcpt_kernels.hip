@@ -287,12 +287,13 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n
                                                           uint4 *__restrict__ hit) {
     __shared__ int32_t stk[STK][kBlock];
     const int tid = threadIdx.x;
-    const uint32_t i = blockIdx.x * kBlock + tid;
     const uint32_t n = n_dev ? *n_dev : n_host;
-    if (i >= n) return;
-    const Ray r = make_ray(ld3(ray_o[i]), ld3(ray_d[i]));
-    const TraceResult tr = traverse<false, STK>(S, r, 0.f, stk, tid);
-    hit[i] = pack_hit(tr.t, tr.prim, tr.mat_bits);
+    // grid-stride: when the length is only known on the device the host sizes the grid from an estimate
+    for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += gridDim.x * kBlock) {
+        const Ray r = make_ray(ld3(ray_o[i]), ld3(ray_d[i]));
+        const TraceResult tr = traverse<false, STK>(S, r, 0.f, stk, tid);
+        hit[i] = pack_hit(tr.t, tr.prim, tr.mat_bits);
+    }
 }
 
 // Shadow queue consumer: a fixed grid strides over the queue, whose length is only known on the device.
@@ -810,12 +811,13 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
 // adds nothing to l_dir whether it is visible or not, so it casts no shadow ray; a NaN contribution is not zero
 // and is traced.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wave next, Scratch Xs, int next_idx) {
+__global__ __launch_bounds__(kBlock, 8) void k_direct(DevScene S, RenderConst C, Wave next, Scratch Xs, int next_idx) {
     __shared__ BlockAllocShared sh;
-    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t n_dir = (uint32_t)C.n_dir;
-    const uint32_t n_vertices = C.counters->n_direct[next_idx].v;  // the grid is an upper bound
-    const bool valid = g < n_vertices * n_dir;
+    const uint32_t total = C.counters->n_direct[next_idx].v * n_dir;  // the grid is sized from an estimate: stride over the list
+    for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {  // uniform trip count per block
+    const uint32_t g = base + threadIdx.x;
+    const bool valid = g < total;
     bool cast = false, window = false;
     f3 q = mk3(0, 0, 0), ws = mk3(0, 0, 1);
     float dist = 0.f;
@@ -882,6 +884,8 @@ __global__ __launch_bounds__(kBlock) void k_direct(DevScene S, RenderConst C, Wa
         const uint32_t e = window ? (uint32_t)C.pool * (uint32_t)C.n_dir - 1u - idx[1] : idx[0];
         Xs.shq_o[e] = make_float4(q.x, q.y, q.z, __uint_as_float(target));
         Xs.shq_d[e] = make_float4(ws.x, ws.y, ws.z, dist);
+    }
+    __syncthreads();  // `sh` is reused by the next round
     }
 }
 
@@ -985,9 +989,9 @@ void launch_trace_closest(const DevScene &S, uint32_t n, const uint32_t *n_dev, 
     else hipLaunchKernelGGL((k_trace_closest<kMaxBvhHeight>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
 }
 
-void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_max, hipStream_t s) {
-    if (n_vertices_max == 0) return;
-    hipLaunchKernelGGL(k_direct, dim3(blocks(n_vertices_max * (uint32_t)C.n_dir)), dim3(kBlock), 0, s, S, C, next, X, next_idx);
+void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_grid, hipStream_t s) {
+    if (n_vertices_grid == 0) return;
+    hipLaunchKernelGGL(k_direct, dim3(blocks(n_vertices_grid * (uint32_t)C.n_dir)), dim3(kBlock), 0, s, S, C, next, X, next_idx);
 }
 
 void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, uint32_t cap, Scratch X,
