@@ -199,6 +199,24 @@ def test_two_pools_match_one_pool(pkg, hip, monkeypatch):
     assert st2.vertices == st1.vertices and st2.shaded == st1.shaded and st2.shadow_rays == st1.shadow_rays
 
 
+def test_host_schedule_variants_are_bit_identical(pkg, hip, monkeypatch):
+    """The frame does not depend on how the host drives the loop: kernels queued ahead of the counter read-back
+    (default) or after it, a slow host (test hook), one stream instead of three, a tight pool that forces many
+    regeneration rounds."""
+    sd = pkg.scenes.cornell_demo(96, 96, 8)
+    ref, st0 = hip.HipScene(sd).render(spp=8, seed=9, spp_per_pass=4)
+    for env, kw in [({"MCPT_QUEUE_AHEAD": "0"}, {}), ({"MCPT_HOST_DELAY_US": "200"}, {}),
+                    ({"MCPT_QUEUE_AHEAD": "1"}, {"pool_paths": 3 * 4096}), ({"MCPT_QUEUE_AHEAD": "0"}, {"pool_paths": 3 * 4096}),
+                    ({"MCPT_OVERLAP": "0"}, {"pool_paths": 3 * 4096})]:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        fb, st = hip.HipScene(sd).render(spp=8, seed=9, spp_per_pass=4, **kw)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.array_equal(ref, fb, equal_nan=True), (env, kw)
+        assert (st.vertices, st.shaded, st.shadow_rays, st.closest_rays) == (st0.vertices, st0.shaded, st0.shadow_rays, st0.closest_rays)
+
+
 def test_progressive_accumulation_matches_single_call(pkg, hip):
     sd = pkg.scenes.cornell_rc(64, 64, 8)
     hs = hip.HipScene(sd)
