@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects the profiles of a round on the GPU box: tools/profile_round.sh TAG  (outputs under gpurun_out/prof_TAG/)
+set -o pipefail
+TAG=${1:-vX}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench.json 2> $O/bench.err || exit 1
+echo "bench done"; tail -c 400 $O/bench.json; echo
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline --no-psnr > $O/kt.log 2>&1 || exit 1
+f=$(find $O/kt -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_overlap.csv
+t=$(find $O/kt -name "*kernel_trace.csv" | head -1); python3 $R/tools/trace_busy.py $t 0.3 > $O/trace_busy_overlap.txt
+rm -rf $O/kt; echo "kernel trace done"
+export MCPT_OVERLAP=0
+SMALL="--steps 1 --warmup 0 --spp-per-step 64 --no-cpu-baseline --no-psnr"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt0 -- python3 $R/bench.py $SMALL > $O/kt0.log 2>&1 || exit 1
+f=$(find $O/kt0 -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_no_overlap_64spp.csv; rm -rf $O/kt0
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
+  n=$(echo $C | tr ' ' '_')
+  rocprofv3 --pmc $C --output-format csv -d $O/pmc_$n -- python3 $R/bench.py $SMALL > $O/pmc_$n.log 2>&1 || { tail -3 $O/pmc_$n.log; exit 1; }
+  f=$(find $O/pmc_$n -name "*counter_collection.csv" | head -1); cp $f $O/pmc_$n.csv; rm -rf $O/pmc_$n
+  echo "pmc $n done"
+done
+python3 $R/profiles/summarize_pmc.py $O/pmc_*.csv > $O/pmc_summary_no_overlap_64spp_step.json
+rm -f $O/pmc_*.csv
+ls -la $O
