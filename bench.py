@@ -8,9 +8,10 @@ n_dir_sample = 4 as the reference executes; pass --n-dir 32 for the README's lab
 A "step" is one pass of --spp-per-step samples per pixel over the whole frame, accumulated into the
 device framebuffer (progressive rendering: K steps = K*spp_per_step spp of the same frame).  The defaults
 (8 steps x 256 spp) are the full 1920x1080, spp = 2048 frame the metric is quoted on.  The K timed steps are
-issued as ONE mcpt_render_device call with spp = K*spp_per_step and spp_per_pass = spp_per_step: the library keeps
-two passes in flight, so the drain tail of a step overlaps the start of the next one (--per-step-calls issues one
-call per step instead).  The scene
+issued as ONE mcpt_render_device call with spp = K*spp_per_step and spp_per_pass = spp_per_step * N ranks (a rank owns
+1/N of the pixels, so a pass is the same amount of work -- and the same per-pass result buffer -- at any N): the library
+keeps two passes in flight, so the drain tail of a pass overlaps the start of the next one (--per-step-calls issues
+one call per step instead).  The scene
 is resident in HBM before the timed region.  With N ranks the frame is partitioned into interleaved
 32x32 pixel tiles (strong scaling: the frame is fixed), every rank renders its tiles, and the timed
 region ends with one RCCL reduce of the framebuffer to rank 0 (torch.distributed, backend nccl).
@@ -139,7 +140,7 @@ def main():
     def step(k, spp_total, accumulate, n_steps=1):
         return hs.render_device(fb.data_ptr(), stream.cuda_stream, spp=spp_step * n_steps, spp_total=spp_total,
                                 sample_offset=k * spp_step, accumulate=accumulate, seed=1, tile_size=32,
-                                rank=rank, nranks=world, n_dir_sample=args.n_dir, spp_per_pass=spp_step,
+                                rank=rank, nranks=world, n_dir_sample=args.n_dir, spp_per_pass=spp_step * world,
                                 pool_paths=args.pool_paths)
 
     def barrier():

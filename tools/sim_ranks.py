@@ -7,15 +7,16 @@ hs = pkg.HipScene(sd, device=0)
 fb = torch.zeros(1920*1080*3, dtype=torch.float32, device='cuda')
 st = torch.cuda.current_stream()
 PER_STEP = "--per-step-calls" in sys.argv
-def run(nranks, steps=4):
-    hs.render_device(fb.data_ptr(), st.cuda_stream, spp=256, spp_total=1024, accumulate=0, rank=0, nranks=nranks, spp_per_pass=256)
+SCALE_PASS = "--scale-pass" in sys.argv  # spp per pass grows with the rank count (constant work per pass)
+def run(nranks, steps=8):
+    hs.render_device(fb.data_ptr(), st.cuda_stream, spp=256, spp_total=2048, accumulate=0, rank=0, nranks=nranks, spp_per_pass=256)
     torch.cuda.synchronize(); t=time.perf_counter(); its=0
     if PER_STEP:
         for k in range(steps):
-            s = hs.render_device(fb.data_ptr(), st.cuda_stream, spp=256, spp_total=1024, sample_offset=k*256, accumulate=1, rank=0, nranks=nranks, spp_per_pass=256)
+            s = hs.render_device(fb.data_ptr(), st.cuda_stream, spp=256, spp_total=2048, sample_offset=k*256, accumulate=1, rank=0, nranks=nranks, spp_per_pass=256)
             its += s.iterations
     else:  # one call, passes pipelined inside the library (what bench.py does)
-        its = hs.render_device(fb.data_ptr(), st.cuda_stream, spp=256*steps, spp_total=1024, accumulate=1, rank=0, nranks=nranks, spp_per_pass=256).iterations
+        its = hs.render_device(fb.data_ptr(), st.cuda_stream, spp=256*steps, spp_total=2048, accumulate=1, rank=0, nranks=nranks, spp_per_pass=(256*nranks if SCALE_PASS else 256)).iterations
     torch.cuda.synchronize(); dt=(time.perf_counter()-t)/steps
     return dt*1e3, its/steps
 base,_ = run(1)
