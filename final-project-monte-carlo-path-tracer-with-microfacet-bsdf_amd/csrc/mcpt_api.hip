@@ -327,7 +327,8 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     const int n_dir = C.n_dir;
     const int P = (int)plan.size();
     C.track_live = (acc && P > 1) ? 1 : 0;
-    launch_init_free(w.free_slots.p, w.counters.p, pool, st);
+    const char *rs = std::getenv("MCPT_RING_START");  // test hook: start the ring counters near 2^32
+    launch_init_free(w.free_slots.p, w.counters.p, pool, rs ? (uint32_t)std::strtoul(rs, nullptr, 0) : 0u, w.free_ring - 1u, st);
     if (ctx.side[1]) {  // fork: the side streams start after everything queued on `st` so far (counters, pixel list, framebuffer)
         HIP_TRY(hipEventRecord(ctx.book, st));
         for (int k = 0; k < 2; ++k) HIP_TRY(hipStreamWaitEvent(ctx.side[k], ctx.book, 0));

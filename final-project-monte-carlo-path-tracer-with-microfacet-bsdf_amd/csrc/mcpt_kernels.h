@@ -89,7 +89,7 @@ struct CameraConst {
     float orient[9];
 };
 
-void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, hipStream_t s);
+void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, uint32_t start, uint32_t mask, hipStream_t s);
 // After k_shade(cur -> next): adds this iteration's list lengths to the cumulative totals and clears the counters of
 // list `cur` (consumed; it is the next iteration's output list), in one launch.
 void launch_bookkeep(Counters *c, int cur_idx, bool from_host, uint32_t n_next, uint32_t n_cont, uint32_t n_direct, hipStream_t s);

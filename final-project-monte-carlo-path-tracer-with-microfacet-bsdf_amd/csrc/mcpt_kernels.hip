@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kBlock) void k_generate_explicit(Wave next, Counter
     if (j == 0) {
         c->n_paths[next_idx].v = n;
         c->n_rays[next_idx].v = n;
-        c->free_head.v = n;  // slots 0 .. n-1 are taken (record j owns slot j)
+        c->free_head.v += n;  // the first n ring entries hold slots 0 .. n-1 (record j owns slot j)
     }
     if (j >= n) return;
     next.rec0[j] = make_uint4(j, j, kFresh, 0u);
@@ -465,14 +465,15 @@ __global__ __launch_bounds__(kBlock) void k_camera_rays(CameraConst cam, uint32_
     d[j] = make_float4(dir.x, dir.y, dir.z, 0.f);
 }
 
-__global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Counters *c, uint32_t pool) {
+// `start`: initial value of the ring's head counter (0; a test hook starts it just below 2^32 to exercise the wrap).
+__global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, uint32_t start, uint32_t mask) {
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
-    if (j < pool) free_slots[j] = j;
+    if (j < pool) free_slots[(start + j) & mask] = j;
     if (j == 0) {
         c->n_paths[0].v = c->n_paths[1].v = 0;
         c->n_rays[0].v = c->n_rays[1].v = 0;
-        c->free_head.v = 0;
-        c->free_tail.v = pool;
+        c->free_head.v = start;
+        c->free_tail.v = start + pool;
         c->n_prays[0].v = c->n_prays[1].v = 0;
         c->live[0].v = c->live[1].v = 0;
         c->n_shadow[0].v = c->n_shadow[1].v = 0;
@@ -951,8 +952,8 @@ void launch_bookkeep(Counters *c, int cur_idx, bool from_host, uint32_t n_next, 
     hipLaunchKernelGGL(k_bookkeep, dim3(1), dim3(64), 0, s, c, cur_idx, from_host ? 1 : 0, n_next, n_cont, n_direct);
 }
 
-void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, hipStream_t s) {
-    hipLaunchKernelGGL(k_init_free, dim3(blocks(pool)), dim3(kBlock), 0, s, free_slots, c, pool);
+void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, uint32_t start, uint32_t mask, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_free, dim3(blocks(pool)), dim3(kBlock), 0, s, free_slots, c, pool, start, mask);
 }
 
 void launch_primary(const DevScene &S, const CameraConst &cam, const RenderConst &C, Wave next, int next_idx, int parity,

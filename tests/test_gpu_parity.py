@@ -207,7 +207,9 @@ def test_host_schedule_variants_are_bit_identical(pkg, hip, monkeypatch):
     ref, st0 = hip.HipScene(sd).render(spp=8, seed=9, spp_per_pass=4)
     for env, kw in [({"MCPT_QUEUE_AHEAD": "0"}, {}), ({"MCPT_HOST_DELAY_US": "200"}, {}),
                     ({"MCPT_QUEUE_AHEAD": "1"}, {"pool_paths": 3 * 4096}), ({"MCPT_QUEUE_AHEAD": "0"}, {"pool_paths": 3 * 4096}),
-                    ({"MCPT_OVERLAP": "0"}, {"pool_paths": 3 * 4096})]:
+                    ({"MCPT_OVERLAP": "0"}, {"pool_paths": 3 * 4096}),
+                    # the free-slot ring's 32-bit head/tail counters wrap in the middle of the run (they do once per full frame)
+                    ({"MCPT_RING_START": "0xffffc000"}, {"pool_paths": 3 * 4096}), ({"MCPT_RING_START": "0xfffffff0"}, {})]:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         fb, st = hip.HipScene(sd).render(spp=8, seed=9, spp_per_pass=4, **kw)
