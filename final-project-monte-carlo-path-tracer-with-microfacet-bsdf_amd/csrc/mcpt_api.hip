@@ -342,6 +342,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     // continuation rays / direct-lighting vertices per record, as observed in the last iteration: they size the grids of the
     // kernels that are queued before the host knows the true lengths (grid-stride kernels: any grid is correct)
     double cont_ratio = 1.0, direct_ratio = 1.0;
+    bool n_cur_exact = false;  // n_cur_max is the true list length (false right after the prologue: an upper bound)
     long it = 0;
     std::vector<long> issue_done_iter(P, -1);
     hipStream_t s_close = ctx.side[0] ? ctx.side[0] : st, s_prim = ctx.side[1] ? ctx.side[1] : st;
@@ -445,8 +446,9 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             T.collect();
-        have_counters = true;
+            have_counters = true;
             n_cur_max = w.h_counters->n_paths[cur].v;
+            n_cur_exact = true;
             accumulate_done(st);
             continue;
         }
@@ -493,8 +495,10 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             const int rc = wait_counters();
             if (rc != MCPT_OK) return rc;
         }
-        const uint32_t grid_cont = !queue_ahead ? n_cont : std::min<uint32_t>(n_cur_max, (uint32_t)(1.15 * cont_ratio * n_cur_max) + 4096u);
-        const uint32_t grid_direct = !queue_ahead ? n_direct : std::min<uint32_t>(n_cur_max, (uint32_t)(1.15 * direct_ratio * n_cur_max) + 4096u);
+        // (+25 %, and never fewer than 2048 workgroups' worth of lanes: a grid that is too small still works, but loses balance)
+        const uint32_t grid_floor = std::min<uint32_t>(n_cur_max, 2048u * 256u);
+        const uint32_t grid_cont = !queue_ahead ? n_cont : std::max<uint32_t>(grid_floor, std::min<uint32_t>(n_cur_max, (uint32_t)(1.25 * cont_ratio * n_cur_max) + 4096u));
+        const uint32_t grid_direct = !queue_ahead ? n_direct : std::max<uint32_t>(grid_floor, std::min<uint32_t>(n_cur_max, (uint32_t)(1.25 * direct_ratio * n_cur_max) + 4096u));
         if (grid_cont > 0) {
             if (ctx.side[0]) HIP_TRY(hipStreamWaitEvent(s_close, ctx.shaded, 0));
             ev = T.begin(s_close);
@@ -526,10 +530,13 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
         const uint32_t n_next = w.h_counters->n_paths[nxt].v;  // shaded + fresh records
         free_known = w.h_counters->free_tail.v - w.h_counters->free_head.v;
         if (n_cur_max > 0) {
-            cont_ratio = (double)n_cont / n_cur_max;
-            direct_ratio = (double)n_direct / n_cur_max;
+            if (n_cur_exact) {  // (an upper bound in the denominator would under-size the next grids)
+                cont_ratio = (double)n_cont / n_cur_max;
+                direct_ratio = (double)n_direct / n_cur_max;
+            }
         }
         n_cur_max = n_next;
+        n_cur_exact = true;
         cur = nxt;
     }
     // the last shadow queue was consumed after the last k_bookkeep: fold it into the totals
