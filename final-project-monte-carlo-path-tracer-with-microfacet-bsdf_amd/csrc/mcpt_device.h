@@ -36,7 +36,8 @@ MCPT_DI f3 normalized(f3 a) {  // Eigen normalized(): unchanged when the squared
     return a;
 }
 MCPT_DI float comp(f3 a, int c) { return c == 0 ? a.x : (c == 1 ? a.y : a.z); }
-MCPT_DI float comp(const float *a, int c) { return a[c]; }
+// (selects, not a[c]: a dynamically indexed member forces the whole material record into scratch/LDS)
+MCPT_DI float comp(const float *a, int c) { return c == 0 ? a[0] : (c == 1 ? a[1] : a[2]); }
 
 // std::min / std::max / clamp of reference global.hpp:16-18 (a NaN v comes out as hi)
 MCPT_DI float std_min(float a, float b) { return (b < a) ? b : a; }
@@ -224,7 +225,7 @@ MCPT_DI float G1_SmithGGX(f3 v, f3 n, float alpha) {  // Material.hpp:38-69
 MCPT_DI float G_SmithGGX(f3 wi, f3 wo, f3 n, float alpha) { return G1_SmithGGX(wi, n, alpha) * G1_SmithGGX(wo, n, alpha); }  // :70-77
 
 MCPT_DI float get_reflectance(const MaterialRec &m, f2 uv, int ch) {  // Material.hpp:134-151
-    if (!m.textured) return m.refl[ch];
+    if (!m.textured) return comp(m.refl, ch);
     const int col = (int)((uv.x - 0.05f) * 10);
     const int row = (int)((uv.y - 0.00f) * 12);
     if (col >= 3 && col <= 5 && row <= 7) {
