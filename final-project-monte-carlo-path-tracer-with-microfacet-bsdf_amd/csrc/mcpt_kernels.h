@@ -42,7 +42,7 @@ struct Counters {
 struct Wave {
     uint4 *rec0;      // {pid, ray index, depth|flags, kr bits}
     float4 *rec1;     // {eval, |wo.n| or -1 for Dirac, pdf, clamp-stack slot bits}; not written for kTerminate records,
-                      // which keep the slot in rec0.y (they have no ray)
+                      // which keep the slot in rec0.y (they have no ray), nor for fresh ones (slot in rec0.w)
     float4 *ray_o;    // closest-hit queue: origin
     float4 *ray_d;    // closest-hit queue: direction
     uint4 *hit;       // closest-hit results: {t lo, t hi, prim, 0}

@@ -437,8 +437,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
 #pragma unroll
     for (uint32_t c = 0; c < 3; ++c) {
         const uint32_t slot = C.free_slots[(fi + c) & C.free_mask];
-        next.rec0[pi + c] = make_uint4(s * 3u + c, ri, kFresh | (q ? kPassBit : 0u), 0u);
-        next.rec1[pi + c] = make_float4(0.f, 0.f, 0.f, __uint_as_float(slot));
+        next.rec0[pi + c] = make_uint4(s * 3u + c, ri, kFresh | (q ? kPassBit : 0u), slot);  // fresh: no rec1, the slot rides in .w
     }
 }
 
@@ -451,8 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_generate_explicit(Wave next, Counter
         c->free_head.v += n;  // the first n ring entries hold slots 0 .. n-1 (record j owns slot j)
     }
     if (j >= n) return;
-    next.rec0[j] = make_uint4(j, j, kFresh, 0u);
-    next.rec1[j] = make_float4(0.f, 0.f, 0.f, __uint_as_float(j));
+    next.rec0[j] = make_uint4(j, j, kFresh, j);
 }
 
 __global__ __launch_bounds__(kBlock) void k_camera_rays(CameraConst cam, uint32_t seed, uint32_t n, const uint32_t *pixel,
@@ -629,6 +627,9 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
         depth = r0.z & 0xffffu;
         if (flags & kTerminate) {  // no ray, no BSDF terms: the record is rec0 alone, with the slot where the ray index would be
             slot = r0.y;
+        } else if (flags & kFresh) {  // no BSDF terms either: rec0 alone, with the slot where kr would be
+            ray_idx = r0.y;
+            slot = r0.w;
         } else {
             r1 = cur.rec1[i];
             ray_idx = r0.y;
