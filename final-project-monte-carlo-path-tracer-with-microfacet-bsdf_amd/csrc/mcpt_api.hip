@@ -586,6 +586,8 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     pool64 = std::max<uint64_t>(pool64, 3 * 256);
     // keep the clamp stack within 48 GiB
     while (pool64 * (uint64_t)max_depth * 16ull > (48ull << 30) && pool64 > 3 * 4096) pool64 /= 2;
+    // light-sample indices (record * n_dir + k) are 32-bit
+    while (pool64 * (uint64_t)p.n_dir_sample > (1ull << 31) && pool64 > 3 * 4096) pool64 /= 2;
     pool64 = std::min<uint64_t>(pool64, std::max<uint64_t>(3ull * n_pix * (uint64_t)s_pass, 3 * 256));
     // two pools (each half the paths) once a pass is big enough to keep both busy
     int n_pools = sc->n_pools;
