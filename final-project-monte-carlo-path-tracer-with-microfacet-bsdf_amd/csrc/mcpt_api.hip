@@ -175,6 +175,7 @@ struct mcpt_scene {
     int device = 0;
     mcpt_scene_info info{};
     DevBuf<Node> nodes;
+    DevBuf<QNode> qnodes;
     DevBuf<TriGeom> tri_geom;
     DevBuf<TriShade> tri_shade;
     DevBuf<SphereRec> spheres;
@@ -777,6 +778,7 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
         if (e == hipSuccess) e = upload(buf, vec);
     };
     up(sc->nodes, hs.nodes);
+    if (!hs.qnodes.empty()) up(sc->qnodes, hs.qnodes);
     up(sc->tri_geom, hs.tri_geom);
     up(sc->tri_shade, hs.tri_shade);
     up(sc->spheres, hs.spheres);
@@ -791,6 +793,11 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
     }
     DevScene &v = sc->view;
     v.nodes = sc->nodes.p;
+    v.qnodes = hs.qnodes.empty() ? nullptr : sc->qnodes.p;
+    for (int k = 0; k < 3; ++k) {
+        v.q_origin[k] = hs.q_origin[k];
+        v.q_cell[k] = hs.q_cell[k];
+    }
     v.tri_geom = sc->tri_geom.p;
     v.tri_shade = sc->tri_shade.p;
     v.spheres = sc->spheres.p;
@@ -823,7 +830,7 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
     sc->info.bvh_height = hs.height;
     sc->info.n_lights = v.n_lights;
     sc->info.n_prims = hs.n_triangles + hs.n_objects;
-    sc->info.scene_bytes = sc->nodes.bytes() + sc->tri_geom.bytes() + sc->tri_shade.bytes() + sc->spheres.bytes() +
+    sc->info.scene_bytes = sc->nodes.bytes() + sc->qnodes.bytes() + sc->tri_geom.bytes() + sc->tri_shade.bytes() + sc->spheres.bytes() +
                            sc->mats.bytes() + sc->lights.bytes() + sc->light_nodes.bytes() + sc->light_tris.bytes() +
                            sc->env.bytes();
     *out = sc;
@@ -863,7 +870,7 @@ void mcpt_scene_destroy(mcpt_scene *sc) {
     }
     sc->shared.release();
     if (sc->fork) (void)hipEventDestroy(sc->fork);
-    sc->nodes.release(); sc->tri_geom.release(); sc->tri_shade.release(); sc->spheres.release(); sc->mats.release();
+    sc->nodes.release(); sc->qnodes.release(); sc->tri_geom.release(); sc->tri_shade.release(); sc->spheres.release(); sc->mats.release();
     sc->lights.release(); sc->light_nodes.release(); sc->light_tris.release(); sc->env.release();
     delete sc;
 }

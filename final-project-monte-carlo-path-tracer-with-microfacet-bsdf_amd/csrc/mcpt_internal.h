@@ -26,6 +26,19 @@ struct alignas(16) Node {
 };
 static_assert(sizeof(Node) == 64, "Node must be 64 bytes");
 
+// The same node with both child boxes quantised to a 16-bit grid over the scene's root box: 32 bytes = two 16-byte loads
+// instead of four.  The traversal kernels are bound by the rate of per-lane memory requests (each lane fetches its own node),
+// not by arithmetic, so halving the requests per node visit is what counts.  The quantised boxes are conservative: minima are
+// rounded down and maxima up, by one extra cell, so a quantised box contains the exact one and traversal can only visit
+// more, never miss (the hits themselves come from the exact primitive tests).
+//   words 0..5: u16 pairs {lmin.x,lmin.y} {lmin.z,lmax.x} {lmax.y,lmax.z} {rmin.x,rmin.y} {rmin.z,rmax.x} {rmax.y,rmax.z}
+//   words 6,7:  left, right child references
+struct alignas(16) QNode {
+    uint32_t w[6];
+    int32_t left, right;
+};
+static_assert(sizeof(QNode) == 32, "QNode must be 32 bytes");
+
 // Traversal-side triangle record (48 bytes, three 16-byte loads): what Triangle::getIntersection reads
 // (Triangle.hpp:222-252): v0, e1, e2.
 struct alignas(16) TriGeom {
@@ -101,6 +114,8 @@ static_assert(sizeof(LightTri) == 64, "LightTri must be 64 bytes");
 // Host-side product of scene construction, ready to be copied to the device.
 struct HostScene {
     std::vector<Node> nodes;
+    std::vector<QNode> qnodes;            // quantised copy of `nodes` (empty when the grid would be too coarse)
+    float q_origin[3] = {0, 0, 0}, q_cell[3] = {1, 1, 1};  // box coordinate = q_origin + q * q_cell
     std::vector<TriGeom> tri_geom;
     std::vector<TriShade> tri_shade;
     std::vector<SphereRec> spheres;       // indexed by object index (entries for meshes unused)

@@ -135,8 +135,10 @@ struct TraceState {
 
 // (A while-while variant -- descend until every lane holds a leaf, then test leaves together -- was measured
 // 10-15 % slower on the chess scene and 5-10 % faster on the Cornell box; the simple loop is kept.)
-template <int MODE, int STK, bool FAST>
+template <int MODE, int STK, bool FAST, bool QUANT>
 MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, TraceState &st) {
+    QRay qr;
+    if (QUANT) qr = make_qray(S, r);
     const float margin = dist * 1e-4f + 1e-2f;
     float lim = (MODE == kClosest) ? INFINITY : (dist + margin);
     const float lo = dist - margin;
@@ -151,15 +153,27 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
         else st.nt++;
 #endif
         if (cur >= 0) {
-            const float4 *np = reinterpret_cast<const float4 *>(S.nodes + cur);
-            const float4 a = np[0], b = np[1], c = np[2], e = np[3];
-            const float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
-            const float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
-            const int32_t left = __float_as_int(e.x), right = __float_as_int(e.y);
+            int32_t left, right;
             float tl = 0.f, tr = 0.f, txl = 0.f, txr = 0.f;
+            bool hl, hr;
             // every inner node has two children (the builder only emits an inner node for >= 2 primitives)
-            bool hl = box_hit<FAST>(lmin, lmax, r, tl, txl);
-            bool hr = box_hit<FAST>(rmin, rmax, r, tr, txr);
+            if (QUANT) {  // 32-byte node: two 16-byte requests per lane instead of four
+                const uint4 *np = reinterpret_cast<const uint4 *>(S.qnodes + cur);
+                const uint4 a = np[0], b = np[1];
+                left = (int32_t)b.z;
+                right = (int32_t)b.w;
+                hl = qbox_hit<FAST>(S, r, qr, a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16, a.z & 0xffffu, a.z >> 16, tl, txl);
+                hr = qbox_hit<FAST>(S, r, qr, a.w & 0xffffu, a.w >> 16, b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16, tr, txr);
+            } else {
+                const float4 *np = reinterpret_cast<const float4 *>(S.nodes + cur);
+                const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+                const float lmin[3] = {a.x, a.y, a.z}, lmax[3] = {a.w, b.x, b.y};
+                const float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
+                left = __float_as_int(e.x);
+                right = __float_as_int(e.y);
+                hl = box_hit<FAST>(lmin, lmax, r, tl, txl);
+                hr = box_hit<FAST>(rmin, rmax, r, tr, txr);
+            }
             hl = hl && !(tl > lim);
             hr = hr && !(tr > lim);
             if (MODE == kWindow) {
@@ -242,6 +256,11 @@ MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_
 #ifdef MCPT_TRAVERSAL_STATS
     st.nv = st.nt = st.iters = 0;
 #endif
+#define TL(MODE, FAST)                                                              \
+    do {                                                                            \
+        if (S.qnodes) traverse_loop<MODE, STK, FAST, true>(S, r, dist, stk, tid, st); \
+        else traverse_loop<MODE, STK, FAST, false>(S, r, dist, stk, tid, st);       \
+    } while (0)
     // Wave-uniform choice of the slab-test flavour: the exact NaN-faithful chain only when some lane of the wave
     // has a non-finite reciprocal (a zero direction component); otherwise the bit-identical max3/min3 form.
     const bool plain = __all(ray_is_plain(r)) != 0;
@@ -249,16 +268,16 @@ MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_
         // Scene.cpp:74-75: a light sample counts iff the CLOSEST hit lies within EPSILON of the light distance,
         // i.e. iff some hit lies in the window AND no hit lies at or below dist - EPSILON.
         if (plain) {
-            if (!found) traverse_loop<kWindow, STK, true>(S, r, dist, stk, tid, st);
-            if (st.found && !st.occluded) traverse_loop<kOccluder, STK, true>(S, r, dist, stk, tid, st);
+            if (!found) TL(kWindow, true);
+            if (st.found && !st.occluded) TL(kOccluder, true);
         } else {
-            if (!found) traverse_loop<kWindow, STK, false>(S, r, dist, stk, tid, st);
-            if (st.found && !st.occluded) traverse_loop<kOccluder, STK, false>(S, r, dist, stk, tid, st);
+            if (!found) TL(kWindow, false);
+            if (st.found && !st.occluded) TL(kOccluder, false);
         }
     } else if (plain) {
-        traverse_loop<kClosest, STK, true>(S, r, dist, stk, tid, st);
+        TL(kClosest, true);
     } else {
-        traverse_loop<kClosest, STK, false>(S, r, dist, stk, tid, st);
+        TL(kClosest, false);
     }
 #ifdef MCPT_TRAVERSAL_STATS
     if (S.dbg) {  // [kind*8 + {rays, node visits, prim tests, occluded/hit, wave-iterations*64, found}]

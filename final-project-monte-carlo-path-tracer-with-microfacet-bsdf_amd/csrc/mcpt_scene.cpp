@@ -412,6 +412,61 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) 
         *err = "BVH height exceeds the traversal stack (kMaxBvhHeight)";
         return MCPT_ERR_LIMIT;
     }
+    // quantised nodes (see QNode).  Skipped when a grid cell would not be small against the primitives' boxes (a huge ground
+    // plane in a scene of tiny triangles): inflated leaf boxes would cost more visits than the smaller nodes save.
+    hs.qnodes.clear();
+    const char *qenv = std::getenv("MCPT_QUANT_NODES");
+    if (!hs.nodes.empty() && !(qenv && qenv[0] == '0')) {
+        double origin[3], cell[3];
+        const float rmn[3] = {root->bounds.mn.x, root->bounds.mn.y, root->bounds.mn.z};
+        const float rmx[3] = {root->bounds.mx.x, root->bounds.mx.y, root->bounds.mx.z};
+        bool ok = true;
+        for (int a = 0; a < 3; ++a) {
+            const double ext = (double)rmx[a] - (double)rmn[a];
+            const double pad = ext * 1e-3 + 1e-6;
+            origin[a] = (double)rmn[a] - pad;
+            cell[a] = (ext + 2 * pad) / 65535.0;
+            hs.q_origin[a] = (float)origin[a];
+            hs.q_cell[a] = (float)cell[a];
+            ok = ok && std::isfinite(ext) && hs.q_cell[a] > 0.f;
+        }
+        // median leaf-box diagonal against the cell diagonal
+        std::vector<float> diag;
+        diag.reserve(hs.nodes.size());
+        for (const Node &N : hs.nodes) {
+            if (N.left < 0 && N.left != kNoChild) diag.push_back(std::sqrt((N.lmax[0] - N.lmin[0]) * (N.lmax[0] - N.lmin[0]) + (N.lmax[1] - N.lmin[1]) * (N.lmax[1] - N.lmin[1]) + (N.lmax[2] - N.lmin[2]) * (N.lmax[2] - N.lmin[2])));
+            if (N.right < 0 && N.right != kNoChild) diag.push_back(std::sqrt((N.rmax[0] - N.rmin[0]) * (N.rmax[0] - N.rmin[0]) + (N.rmax[1] - N.rmin[1]) * (N.rmax[1] - N.rmin[1]) + (N.rmax[2] - N.rmin[2]) * (N.rmax[2] - N.rmin[2])));
+        }
+        if (!diag.empty()) {
+            std::nth_element(diag.begin(), diag.begin() + diag.size() / 2, diag.end());
+            const double cd = std::sqrt(cell[0] * cell[0] + cell[1] * cell[1] + cell[2] * cell[2]);
+            ok = ok && (cd * 8.0 <= (double)diag[diag.size() / 2] || (qenv && qenv[0] == '1'));
+        }
+        if (ok) {
+            // the device dequantises in float: x = q_origin + q * q_cell; one extra cell on each side covers its rounding
+            auto qlo = [&](float v, int a) {
+                const double q = std::floor(((double)v - (double)hs.q_origin[a]) / (double)hs.q_cell[a]) - 1.0;
+                return (uint32_t)std::min(65535.0, std::max(0.0, q));
+            };
+            auto qhi = [&](float v, int a) {
+                const double q = std::ceil(((double)v - (double)hs.q_origin[a]) / (double)hs.q_cell[a]) + 1.0;
+                return (uint32_t)std::min(65535.0, std::max(0.0, q));
+            };
+            hs.qnodes.resize(hs.nodes.size());
+            for (size_t i = 0; i < hs.nodes.size(); ++i) {
+                const Node &N = hs.nodes[i];
+                QNode &Q = hs.qnodes[i];
+                Q.w[0] = qlo(N.lmin[0], 0) | (qlo(N.lmin[1], 1) << 16);
+                Q.w[1] = qlo(N.lmin[2], 2) | (qhi(N.lmax[0], 0) << 16);
+                Q.w[2] = qhi(N.lmax[1], 1) | (qhi(N.lmax[2], 2) << 16);
+                Q.w[3] = qlo(N.rmin[0], 0) | (qlo(N.rmin[1], 1) << 16);
+                Q.w[4] = qlo(N.rmin[2], 2) | (qhi(N.rmax[0], 0) << 16);
+                Q.w[5] = qhi(N.rmax[1], 1) | (qhi(N.rmax[2], 2) << 16);
+                Q.left = N.left;
+                Q.right = N.right;
+            }
+        }
+    }
     if (hs.nodes.empty()) {  // keep the device array non-empty
         hs.nodes.emplace_back();
         std::memset(&hs.nodes[0], 0, sizeof(Node));
