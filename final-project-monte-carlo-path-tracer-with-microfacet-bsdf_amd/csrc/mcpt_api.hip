@@ -793,6 +793,7 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
     }
     DevScene &v = sc->view;
     v.nodes = sc->nodes.p;
+    v.light_area_sum = hs.light_area_sum;
     v.qnodes = hs.qnodes.empty() ? nullptr : sc->qnodes.p;
     for (int k = 0; k < 3; ++k) {
         v.q_origin[k] = hs.q_origin[k];

@@ -93,7 +93,7 @@ struct DevScene {
     const float *env;
     float root_min[3], root_max[3];
     float background[3];
-    float light_center[3], light_radius;
+    float light_center[3], light_radius, light_area_sum;
     int32_t root, n_tri, n_lights, env_w, env_h, height;
     unsigned long long *dbg;  // traversal statistics (only written by -DMCPT_TRAVERSAL_STATS builds)
 };

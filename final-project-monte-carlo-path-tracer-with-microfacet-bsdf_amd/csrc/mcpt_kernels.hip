@@ -509,8 +509,7 @@ __global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Coun
 // u = {light choice, triangle pick, x, y}.  Returns false when no light was selected.
 // ------------------------------------------------------------------------------------------------
 MCPT_DI bool sample_light(const DevScene &S, const float u[4], f3 &x_l, f3 &n_l, f3 &emit, float &pdf, int32_t &prim) {
-    float area_sum = 0.f;
-    for (int k = 0; k < S.n_lights; ++k) area_sum += S.lights[k].area;
+    float area_sum = S.light_area_sum;  // Scene.cpp:24-27: the sum over the emitters in insertion order (computed once, on the host)
     const float p = u[0] * area_sum;
     area_sum = 0.f;
     for (int k = 0; k < S.n_lights; ++k) {
@@ -660,8 +659,14 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
         if (!(flags & kFresh)) {
             // ---- resolve the pending vertex: Scene.cpp:114-119 (l_dir), 129-149 / 156-176 (l_ind)
             float dl = 0.f;
-            if (!(flags & kNoDirect))
-                for (int k = 0; k < C.n_dir; ++k) dl += cur.contrib[(size_t)i * C.n_dir + k];  // Scene.cpp:76 `l_dir +=`, in order
+            if (!(flags & kNoDirect)) {
+                if (C.n_dir == 4) {  // one 16-byte request instead of four dwords; same sum, same order (Scene.cpp:76 `l_dir +=`)
+                    const float4 c4 = reinterpret_cast<const float4 *>(cur.contrib)[i];
+                    dl = (((dl + c4.x) + c4.y) + c4.z) + c4.w;
+                } else {
+                    for (int k = 0; k < C.n_dir; ++k) dl += cur.contrib[(size_t)i * C.n_dir + k];  // Scene.cpp:76 `l_dir +=`, in order
+                }
+            }
             const float kr = __uint_as_float(r0.w);
             const float l_dir = (flags & kInside) ? (float)((1. - (double)kr) * (double)dl) : kr * dl;
             if (flags & kTerminate) {
