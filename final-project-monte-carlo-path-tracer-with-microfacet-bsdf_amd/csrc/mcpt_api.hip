@@ -876,6 +876,48 @@ void mcpt_scene_destroy(mcpt_scene *sc) {
     delete sc;
 }
 
+int mcpt_bvh_dump(const mcpt_scene_desc *desc, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes) {
+    if (!desc || !info) return fail(MCPT_ERR_ARG, "mcpt_bvh_dump: null argument");
+    HostScene hs;
+    const char *err = "";
+    const int rc = build_host_scene(*desc, hs, &err);
+    if (rc != MCPT_OK) return fail(rc, std::string("mcpt_bvh_dump: ") + err);
+    std::memset(info, 0, sizeof *info);
+    const bool placeholder = hs.root < 0;  // a single primitive: no inner node (the array holds one unused record)
+    info->n_nodes = placeholder ? 0 : (int32_t)hs.nodes.size();
+    info->root = hs.root;
+    info->stack_entries = hs.height;
+    info->quantised = hs.qnodes.empty() ? 0 : 1;
+    for (int k = 0; k < 3; ++k) {
+        info->root_min[k] = hs.root_min[k];
+        info->root_max[k] = hs.root_max[k];
+        info->q_origin[k] = hs.q_origin[k];
+        info->q_cell[k] = hs.q_cell[k];
+    }
+    if (!boxes || !children) return MCPT_OK;
+    for (int32_t i = 0; i < info->n_nodes; ++i) {
+        const Node &N = hs.nodes[i];
+        float *b = boxes + (size_t)i * 12;
+        for (int k = 0; k < 3; ++k) {
+            b[k] = N.lmin[k];
+            b[3 + k] = N.lmax[k];
+            b[6 + k] = N.rmin[k];
+            b[9 + k] = N.rmax[k];
+        }
+        children[2 * i] = N.left;
+        children[2 * i + 1] = N.right;
+        if (qboxes && info->quantised) {
+            const QNode &Q = hs.qnodes[i];
+            uint16_t *q = qboxes + (size_t)i * 12;
+            for (int w = 0; w < 6; ++w) {
+                q[2 * w] = (uint16_t)(Q.w[w] & 0xffffu);
+                q[2 * w + 1] = (uint16_t)(Q.w[w] >> 16);
+            }
+        }
+    }
+    return MCPT_OK;
+}
+
 int mcpt_scene_get_info(const mcpt_scene *sc, mcpt_scene_info *info) {
     if (!sc || !info) return fail(MCPT_ERR_ARG, "mcpt_scene_get_info: null argument");
     *info = sc->info;

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCPT_LIB") or os.path.join(HERE, "libmcpt_hip.so")  # MCPT_LIB: diagnostic builds only
 
 EXPORTS = ["mcpt_scene_create", "mcpt_scene_destroy", "mcpt_render", "mcpt_render_device", "mcpt_intersect",
-           "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_last_error", "mcpt_version"]
+           "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_bvh_dump", "mcpt_last_error", "mcpt_version"]
 
 
 class McptError(RuntimeError):
@@ -73,6 +73,8 @@ def lib():
         L.mcpt_scene_destroy.argtypes = [C.c_void_p]
         L.mcpt_scene_get_info.restype = C.c_int
         L.mcpt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
+        L.mcpt_bvh_dump.restype = C.c_int
+        L.mcpt_bvh_dump.argtypes = [C.POINTER(SceneDesc), C.POINTER(BvhInfo), C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcpt_render.restype = C.c_int
         L.mcpt_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]
         L.mcpt_render_device.restype = C.c_int
@@ -97,22 +99,49 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class BvhInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("root", C.c_int32), ("stack_entries", C.c_int32), ("quantised", C.c_int32),
+                ("root_min", C.c_float * 3), ("root_max", C.c_float * 3), ("q_origin", C.c_float * 3), ("q_cell", C.c_float * 3)]
+
+
+def _make_desc(sd, keep):
+    """SceneDesc over the arrays of a scenes.SceneData; `keep` receives the arrays that must outlive the call."""
+    tri, mat, obj = np.ascontiguousarray(sd.triangles), np.ascontiguousarray(sd.materials), np.ascontiguousarray(sd.objects)
+    keep.extend([tri, mat, obj])
+    d = SceneDesc()
+    d.n_objects, d.n_triangles, d.n_materials = len(obj), len(tri), len(mat)
+    d.background = (C.c_float * 3)(*[float(x) for x in sd.background])
+    d.objects, d.triangles, d.materials = _ptr(obj), _ptr(tri), _ptr(mat)
+    if sd.env_pixels is not None:
+        env = np.ascontiguousarray(sd.env_pixels, dtype=np.float32)
+        keep.append(env)
+        d.env_h, d.env_w = env.shape[:2]
+        d.env_pixels = _ptr(env)
+    return d
+
+
+def bvh_dump(sd):
+    """Host-only (no GPU): the traversal tree mcpt_scene_create would build. Returns (info dict, boxes[n,12], children[n,2], qboxes[n,12] or None)."""
+    keep = []
+    d = _make_desc(sd, keep)
+    info = BvhInfo()
+    _check(lib().mcpt_bvh_dump(C.byref(d), C.byref(info), None, None, None))
+    n = info.n_nodes
+    boxes = np.zeros((n, 12), np.float32)
+    children = np.zeros((n, 2), np.int32)
+    qboxes = np.zeros((n, 12), np.uint16)
+    _check(lib().mcpt_bvh_dump(C.byref(d), C.byref(info), _ptr(boxes), _ptr(children), _ptr(qboxes)))
+    out = {k: (list(getattr(info, k)) if k in ("root_min", "root_max", "q_origin", "q_cell") else getattr(info, k)) for k, _ in info._fields_}
+    return out, boxes, children, (qboxes if info.quantised else None)
+
+
 class HipScene:
     """A scene resident in the HBM of one GPU (mcpt_scene_create)."""
 
     def __init__(self, sd, device=-1):
         self.sd = sd
-        self._tri = np.ascontiguousarray(sd.triangles)
-        self._mat = np.ascontiguousarray(sd.materials)
-        self._obj = np.ascontiguousarray(sd.objects)
-        d = SceneDesc()
-        d.n_objects, d.n_triangles, d.n_materials = len(self._obj), len(self._tri), len(self._mat)
-        d.background = (C.c_float * 3)(*[float(x) for x in sd.background])
-        d.objects, d.triangles, d.materials = _ptr(self._obj), _ptr(self._tri), _ptr(self._mat)
-        if sd.env_pixels is not None:
-            self._env = np.ascontiguousarray(sd.env_pixels, dtype=np.float32)
-            d.env_h, d.env_w = self._env.shape[:2]
-            d.env_pixels = _ptr(self._env)
+        self._keep = []
+        d = _make_desc(sd, self._keep)
         h = C.c_void_p()
         self.h = None
         _check(lib().mcpt_scene_create(C.byref(d), int(device), C.byref(h)))

@@ -160,6 +160,20 @@ typedef struct {
 } mcpt_scene_info;
 int mcpt_scene_get_info(const mcpt_scene *scene, mcpt_scene_info *info);
 
+/* Host-only diagnostic (no GPU needed): builds the traversal tree of `desc` exactly as mcpt_scene_create does and copies it
+ * out, so that the builder (the data producer of BVHAccel::recursiveBuild, BVH.cpp:27-93) can be checked on any machine.
+ * Call with boxes == NULL to get the counts, then with arrays of n_nodes entries:
+ *   boxes[n][12]    float  {lmin.xyz, lmax.xyz, rmin.xyz, rmax.xyz} of the two children
+ *   children[n][2]  int32  child >= 0: inner node index; < 0: leaf, primitive id = ~child
+ *   qboxes[n][12]   uint16 the same boxes on the 16-bit grid (only written when info->quantised)
+ * Primitive ids: triangle index, or n_triangles + object index for a sphere. */
+typedef struct {
+    int32_t n_nodes, root, stack_entries, quantised;
+    float root_min[3], root_max[3];
+    float q_origin[3], q_cell[3]; /* grid coordinate q <-> q_origin + q * q_cell */
+} mcpt_bvh_info;
+int mcpt_bvh_dump(const mcpt_scene_desc *desc, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes);
+
 const char *mcpt_last_error(void);
 const char *mcpt_version(void);
 

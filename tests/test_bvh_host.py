@@ -1,0 +1,101 @@
+"""Host-side checks of the BVH builder (the data producer of the hot path) through mcpt_bvh_dump: no GPU needed.
+
+Invariants of the traversal tree that mcpt_scene_create uploads (reference: BVHAccel::recursiveBuild, BVH.cpp:27-93,
+whose two-level topology MCPT_BVH=reference keeps; the default is one binned-SAH tree over all primitives):
+every primitive sits in exactly one leaf, every child box contains what is below it, the declared traversal-stack
+bound covers the tree, and the quantised 16-bit boxes contain the exact ones."""
+import numpy as np
+import pytest
+
+
+def prim_bounds(sd):
+    tri = sd.triangles
+    v = np.stack([tri["v0"], tri["v1"], tri["v2"]], axis=1).astype(np.float32)  # [n, 3, 3]
+    mn, mx = [v.min(axis=1)], [v.max(axis=1)]
+    obj = sd.objects
+    sph_mn = (obj["center"] - obj["radius"][:, None]).astype(np.float32)
+    sph_mx = (obj["center"] + obj["radius"][:, None]).astype(np.float32)
+    return np.concatenate(mn + [sph_mn]), np.concatenate(mx + [sph_mx])  # sphere prim id = n_tri + object index
+
+
+def check_tree(sd, info, boxes, children, qboxes):
+    pmn, pmx = prim_bounds(sd)
+    n_tri = len(sd.triangles)
+    n_prims = n_tri + int((sd.objects["kind"] == 1).sum())
+    seen = np.zeros(len(pmn), np.int32)
+    eps = 1e-5
+
+    def subtree(ref):  # -> (mn, mx, height) of everything below a child reference
+        if ref < 0:
+            p = ~ref
+            seen[p] += 1
+            return pmn[p], pmx[p], 0
+        b = boxes[ref]
+        out_mn, out_mx, h = None, None, 0
+        for side, cref in enumerate(children[ref]):
+            cmn, cmx, ch = subtree(int(cref))
+            box_mn, box_mx = b[6 * side:6 * side + 3], b[6 * side + 3:6 * side + 6]
+            assert (box_mn <= cmn + eps).all() and (box_mx >= cmx - eps).all(), (ref, side)
+            out_mn = box_mn if out_mn is None else np.minimum(out_mn, box_mn)
+            out_mx = box_mx if out_mx is None else np.maximum(out_mx, box_mx)
+            h = max(h, ch)
+        return out_mn, out_mx, h + 1
+
+    import sys
+    sys.setrecursionlimit(10000)
+    mn, mx, height = subtree(info["root"])
+    assert (np.array(info["root_min"]) <= mn + eps).all() and (np.array(info["root_max"]) >= mx - eps).all()
+    used = seen[:n_tri].tolist() + seen[n_tri:][sd.objects["kind"] == 1].tolist()
+    assert all(c == 1 for c in used) and sum(used) == n_prims
+    assert height <= info["stack_entries"]  # near-first traversal leaves at most one entry per level on the stack
+    if qboxes is not None:
+        o = np.array(info["q_origin"], np.float32)
+        c = np.array(info["q_cell"], np.float32)
+        q = qboxes.astype(np.float32).reshape(-1, 4, 3)            # lmin, lmax, rmin, rmax
+        deq = (o + q * c).astype(np.float32)                        # the device's float dequantisation
+        ex = boxes.reshape(-1, 4, 3)
+        assert (deq[:, 0] <= ex[:, 0]).all() and (deq[:, 2] <= ex[:, 2]).all(), "quantised minimum above the exact one"
+        assert (deq[:, 1] >= ex[:, 1]).all() and (deq[:, 3] >= ex[:, 3]).all(), "quantised maximum below the exact one"
+        assert (np.abs(deq - ex) <= 3.01 * c + 1e-6).all(), "quantised box inflated by more than three cells"
+    return height
+
+
+@pytest.mark.parametrize("scene", ["cornell_demo", "cornell_rc", "chess"])
+@pytest.mark.parametrize("topology", ["sah", "reference"])
+def test_tree_invariants(pkg, hip, monkeypatch, scene, topology):
+    if topology == "reference":
+        monkeypatch.setenv("MCPT_BVH", "reference")
+    sd = pkg.scenes.chess_scene(width=64, height=64, spp=1) if scene == "chess" else getattr(pkg.scenes, scene)(64, 64, 1)
+    info, boxes, children, qboxes = hip.bvh_dump(sd)
+    assert info["n_nodes"] == len(boxes) > 0
+    h = check_tree(sd, info, boxes, children, qboxes)
+    if scene == "chess" and topology == "sah":
+        assert info["quantised"] == 1 and h <= 24  # the chess tree fits the 20/24-entry traversal stacks
+
+
+def test_quantisation_can_be_switched_off(pkg, hip, monkeypatch):
+    monkeypatch.setenv("MCPT_QUANT_NODES", "0")
+    info, boxes, children, qboxes = hip.bvh_dump(pkg.scenes.cornell_demo(32, 32, 1))
+    assert info["quantised"] == 0 and qboxes is None
+
+
+def test_random_soup_and_single_primitive(pkg, hip):
+    rng = np.random.default_rng(5)
+    base = pkg.scenes.cornell_rc(32, 32, 1)
+    n = 500
+    tri = np.zeros(n, dtype=base.triangles.dtype)
+    c = rng.uniform(-50, 50, (n, 3)).astype(np.float32)
+    for k in ("v0", "v1", "v2"):
+        tri[k] = c + rng.normal(0, 0.5, (n, 3)).astype(np.float32)
+    obj = np.zeros(1, dtype=base.objects.dtype)
+    obj["kind"], obj["material"], obj["first_tri"], obj["n_tri"] = 0, 0, 0, n
+    sd = pkg.scenes.SceneData(triangles=tri, materials=base.materials[:1].copy(), objects=obj, background=base.background,
+                              env_pixels=None, camera=base.camera, rr_rate=base.rr_rate)
+    info, boxes, children, qboxes = hip.bvh_dump(sd)
+    assert info["n_nodes"] == n - 1  # a binary tree over n single-primitive leaves
+    check_tree(sd, info, boxes, children, qboxes)
+    one = pkg.scenes.SceneData(triangles=tri[:1].copy(), materials=sd.materials, objects=obj.copy(), background=sd.background,
+                               env_pixels=None, camera=sd.camera, rr_rate=sd.rr_rate)
+    one.objects["n_tri"] = 1
+    info, boxes, children, qboxes = hip.bvh_dump(one)
+    assert info["n_nodes"] == 0 and info["root"] == ~0
