@@ -926,7 +926,16 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float *__restrict__
     const uint32_t pl = g / 3u, c = g % 3u;
     const uint32_t m = pixel_list ? pixel_list[pl] : pl;
     float acc = fb[(size_t)m * 3 + c];
-    for (int k = 0; k < s_pass; ++k) acc += result[((size_t)pl * s_pass + k) * 3 + c] / spp_total;
+    const float *src = result + (size_t)pl * s_pass * 3 + c;
+    int k = 0;
+    for (; k + 8 <= s_pass; k += 8) {  // eight loads in flight; the additions stay in sample order (Renderer.cpp:80)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(k + u) * 3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u] / spp_total;
+    }
+    for (; k < s_pass; ++k) acc += src[(size_t)k * 3] / spp_total;
     fb[(size_t)m * 3 + c] = acc;
 }
 

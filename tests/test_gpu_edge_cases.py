@@ -93,3 +93,30 @@ def test_empty_inputs(pkg, hip):
     assert len(out) == 0
     with pytest.raises(hip.McptError):
         hs.cast_rays(np.zeros((1, 3), np.float32), np.ones((1, 3), np.float32), [0], [0], [7])  # channel out of range
+
+
+def test_random_configurations_do_not_depend_on_the_schedule(pkg, hip, monkeypatch):
+    """Random frame sizes, spp, light samples, roulette rates and pass sizes: the frame and the work counters are the same
+    with one stream, wait-then-launch, float nodes, a ring counter that wraps and pools of a few hundred paths; and an
+    odd number of ranks partitions it exactly."""
+    rng = np.random.default_rng(3)
+    for _ in range(6):
+        scene = str(rng.choice(["cornell_demo", "cornell_rc", "chess"]))
+        w, h, spp = int(rng.integers(1, 90)), int(rng.integers(1, 70)), int(rng.integers(1, 20))
+        sd = pkg.scenes.chess_scene(width=w, height=h, spp=spp) if scene == "chess" else getattr(pkg.scenes, scene)(w, h, spp)
+        sd.rr_rate = float(rng.choice([0.2, 0.4, 0.7, 0.95]))
+        kw = dict(spp=spp, seed=int(rng.integers(0, 1000)), n_dir_sample=int(rng.choice([1, 2, 4, 5, 9])), spp_per_pass=int(rng.integers(1, spp + 1)))
+        ref, st0 = hip.HipScene(sd).render(**kw)
+        for env, extra in [({"MCPT_OVERLAP": "0"}, {}), ({"MCPT_QUEUE_AHEAD": "0"}, {"pool_paths": 3 * 256}),
+                           ({"MCPT_QUANT_NODES": "0"}, {"pool_paths": 3 * 1024}), ({"MCPT_RING_START": "0xffffff00"}, {"pool_paths": 3 * 512})]:
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            fb, st = hip.HipScene(sd).render(**kw, **extra)
+            for k in env:
+                monkeypatch.delenv(k)
+            assert np.array_equal(ref, fb, equal_nan=True), (scene, w, h, kw, env, extra)
+            assert (st.vertices, st.shaded, st.shadow_rays) == (st0.vertices, st0.shaded, st0.shadow_rays)
+        nr, ts = int(rng.choice([2, 3, 5, 7])), int(rng.choice([4, 8, 32]))
+        hs = hip.HipScene(sd)
+        parts = [hs.render(**kw, rank=r, nranks=nr, tile_size=ts)[0] for r in range(nr)]
+        assert np.array_equal(ref, sum(parts[1:], parts[0]), equal_nan=True), (scene, w, h, kw, nr, ts)
