@@ -70,9 +70,10 @@ struct WaveBufs {
     DevBuf<uint4> rec0, hit;
     DevBuf<float4> rec1, ray_o, ray_d;
     DevBuf<float> contrib;
-    Wave view() const { return Wave{rec0.p, rec1.p, ray_o.p, ray_d.p, hit.p, contrib.p}; }
+    DevBuf<uint2> fresh;
+    Wave view() const { return Wave{rec0.p, rec1.p, ray_o.p, ray_d.p, hit.p, contrib.p, fresh.p}; }
     void release() {
-        rec0.release(); hit.release(); rec1.release(); ray_o.release(); ray_d.release(); contrib.release();
+        rec0.release(); hit.release(); rec1.release(); ray_o.release(); ray_d.release(); contrib.release(); fresh.release();
     }
 };
 
@@ -225,6 +226,7 @@ hipError_t ensure_workspace(PoolCtx &ctx, uint32_t pool, int32_t n_dir, int32_t 
         if ((e = b.ray_d.alloc(n_rays)) != hipSuccess) return e;
         if ((e = b.hit.alloc(n_rays)) != hipSuccess) return e;
         if ((e = b.contrib.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
+        if ((e = b.fresh.alloc(pool / 3 + 64)) != hipSuccess) return e;
     }
     if ((e = w.vtx0.alloc(pool)) != hipSuccess) return e;
     if ((e = w.vtx1.alloc(pool)) != hipSuccess) return e;
@@ -233,10 +235,13 @@ hipError_t ensure_workspace(PoolCtx &ctx, uint32_t pool, int32_t n_dir, int32_t 
     if ((e = w.shq_o.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
     if ((e = w.shq_d.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
     if ((e = w.stack.alloc((size_t)pool * max_depth)) != hipSuccess) return e;
-    uint32_t ring = 1;
-    while (ring < pool) ring <<= 1;  // free-slot ring: power of two, so that the 32-bit head/tail counters may wrap
+    uint64_t ring = 1;
+    // free-slot ring: a power of two, so that the 32-bit head/tail counters may wrap, and at least twice the pool: the entries
+    // k_primary has popped are read one iteration later (by k_shade) and must not be reached by the pushes made meanwhile
+    // (free + pushed + popped <= 2 * pool)
+    while (ring < 2 * (uint64_t)pool) ring <<= 1;
     if ((e = w.free_slots.alloc(ring)) != hipSuccess) return e;
-    w.free_ring = ring;
+    w.free_ring = (uint32_t)ring;
     w.ray_cap = (uint32_t)n_rays;
     if ((e = w.counters.alloc(1)) != hipSuccess) return e;
     if (!w.h_counters && (e = hipHostMalloc((void **)&w.h_counters, sizeof(Counters))) != hipSuccess) return e;
@@ -448,7 +453,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             HIP_TRY(hipStreamSynchronize(st));
             T.collect();
             have_counters = true;
-            n_cur_max = w.h_counters->n_paths[cur].v;
+            n_cur_max = w.h_counters->n_paths[cur].v + 3u * w.h_counters->n_prays[cur].v;
             n_cur_exact = true;
             accumulate_done(st);
             continue;
@@ -528,7 +533,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             if (rc != MCPT_OK) return rc;
         }
         T.bank ^= 1;
-        const uint32_t n_next = w.h_counters->n_paths[nxt].v;  // shaded + fresh records
+        const uint32_t n_next = w.h_counters->n_paths[nxt].v + 3u * w.h_counters->n_prays[nxt].v;  // records + three lanes per new sample
         free_known = w.h_counters->free_tail.v - w.h_counters->free_head.v;
         if (n_cur_max > 0) {
             if (n_cur_exact) {  // (an upper bound in the denominator would under-size the next grids)

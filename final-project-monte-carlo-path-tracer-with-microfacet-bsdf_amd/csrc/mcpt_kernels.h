@@ -28,7 +28,7 @@ struct Counters {
     // `free_tail` (both only ever increase; entry = counter & mask), so the two kernels can run concurrently: the host only
     // lets k_primary pop entries that were pushed by kernels which have already completed.
     HotCounter free_head, free_tail;
-    HotCounter n_prays[2];  // primary rays of list 0 / 1: stored from the END of the ray arrays (they are already traced)
+    HotCounter n_prays[2];  // new samples of list 0 / 1 (Wave::fresh); their rays are stored from the END of the ray arrays
     HotCounter live[2];     // unfinished paths of the pass with that parity (a pass is complete when it reaches 0)
     HotCounter pushes;      // recursion levels entered (castRay depth+1 calls); folded into tot_pushes by k_bookkeep
     HotCounter overflow;    // cumulative: paths cut by max_depth
@@ -47,6 +47,9 @@ struct Wave {
     float4 *ray_d;    // closest-hit queue: direction
     uint4 *hit;       // closest-hit results: {t lo, t hi, prim, 0}
     float *contrib;   // n_dir per path record: light-sample contributions; zeroed by the shadow kernel when invisible
+    uint2 *fresh;     // new samples with a surface hit, entry k (its ray and hit: entry ray_cap-1-k of the ray arrays):
+                      // {sample | pass parity << 31, position of its three slots in the free ring}.  k_shade gives each one
+                      // three lanes (the channel paths) after the records of the list: no per-path record is written for them
 };
 
 // Per-iteration scratch between k_shade, k_direct and k_trace<shadow> (single-buffered: produced and consumed

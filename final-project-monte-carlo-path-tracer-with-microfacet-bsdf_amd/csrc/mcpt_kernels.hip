@@ -439,25 +439,20 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
             }
         }
     }
-    const bool want[4] = {surface, surface, surface, surface && C.track_live};
-    const uint32_t mult[4] = {1u, 3u, 3u, 3u};
-    uint32_t *const ctr[4] = {&C.counters->n_prays[next_idx].v, &C.counters->n_paths[next_idx].v, &C.counters->free_head.v,
-                              &C.counters->live[q].v};  // three more unfinished paths of this pass
-    const bool sub[4] = {false, false, false, false};
-    uint32_t idx[4];
-    block_alloc<4>(sh, want, mult, ctr, sub, idx);
+    const bool want[3] = {surface, surface, surface && C.track_live};
+    const uint32_t mult[3] = {1u, 3u, 3u};
+    uint32_t *const ctr[3] = {&C.counters->n_prays[next_idx].v, &C.counters->free_head.v, &C.counters->live[q].v};  // three more unfinished paths of this pass
+    const bool sub[3] = {false, false, false};
+    uint32_t idx[3];
+    block_alloc<3>(sh, want, mult, ctr, sub, idx);
     if (!surface) return;
-    // the ray is already traced: it goes to the back of the ray arrays, away from the continuation rays that a concurrent
-    // k_shade appends at the front for k_trace_closest
-    const uint32_t ri = C.ray_cap - 1u - idx[0], pi = idx[1], fi = idx[2];
+    // the ray is already traced: it goes to the back of the ray arrays, away from the continuation rays that k_shade appends
+    // at the front for k_trace_closest.  The three channel paths get no records: k_shade derives them from the sample entry.
+    const uint32_t k = idx[0], ri = C.ray_cap - 1u - k;
     next.ray_o[ri] = make_float4(pos.x, pos.y, pos.z, 0.f);
     next.ray_d[ri] = make_float4(dir.x, dir.y, dir.z, 0.f);
     next.hit[ri] = pack_hit(tr.t, tr.prim, tr.mat_bits);
-#pragma unroll
-    for (uint32_t c = 0; c < 3; ++c) {
-        const uint32_t slot = C.free_slots[(fi + c) & C.free_mask];
-        next.rec0[pi + c] = make_uint4(s * 3u + c, ri, kFresh | (q ? kPassBit : 0u), slot);  // fresh: no rec1, the slot rides in .w
-    }
+    next.fresh[k] = make_uint2(s | (q ? 0x80000000u : 0u), idx[1]);
 }
 
 // mcpt_cast_rays: caller-supplied rays, one fresh record per ray; the rays are traced by k_trace_closest.
@@ -624,8 +619,11 @@ MCPT_DI float unwind(const RenderConst &C, uint32_t slot, uint32_t depth, float 
 __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderConst C, Wave cur, Wave next, Scratch Xs, int cur_idx) {
     __shared__ BlockAllocShared sh;
     const uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
-    const uint32_t n_cur = C.counters->n_paths[cur_idx].v;  // the grid is an upper bound; the list length lives on the device
-    const bool valid = i < n_cur;
+    // the grid is an upper bound; the list lengths live on the device.  Lanes [0, n_rec) take the records of the list, the next
+    // 3 * n_new lanes the new samples (one lane per channel path).
+    const uint32_t n_rec = C.counters->n_paths[cur_idx].v, n_new = C.counters->n_prays[cur_idx].v;
+    const bool valid = i < n_rec + 3u * n_new;
+    const bool is_new = valid && i >= n_rec;
     const int next_idx = cur_idx ^ 1;
 
     uint32_t pid = 0, slot = 0, depth = 0, ray_idx = 0;
@@ -638,7 +636,15 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     uint32_t hit_mat = 0;
 
     if (valid) {
-        const uint4 r0 = cur.rec0[i];
+        uint4 r0;
+        if (is_new) {  // a new sample: {sample | parity, ring position of its slots}; its ray is entry ray_cap-1-k
+            const uint32_t k = (i - n_rec) / 3u, c = (i - n_rec) % 3u;
+            const uint2 f = cur.fresh[k];
+            r0 = make_uint4((f.x & 0x7fffffffu) * 3u + c, C.ray_cap - 1u - k, kFresh | ((f.x >> 31) ? kPassBit : 0u),
+                            C.free_slots[(f.y + c) & C.free_mask]);
+        } else {
+            r0 = cur.rec0[i];
+        }
         const uint32_t flags = r0.z;
         float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
         pid = r0.x;
@@ -958,7 +964,7 @@ __global__ void k_bookkeep(Counters *c, int cur_idx, int from_host, uint32_t n_n
         c->tot_shadow += v;
         break;
     }
-    case 1: c->tot_shaded += from_host ? n_next : c->n_paths[nxt].v - 3u * c->n_prays[nxt].v; break;  // fresh records are not shaded vertices
+    case 1: c->tot_shaded += from_host ? n_next : c->n_paths[nxt].v; break;  // (new samples have no records)
     case 2: c->tot_cont += from_host ? n_cont : c->n_rays[nxt].v; break;
     case 3: c->tot_direct += from_host ? n_direct : c->n_direct[nxt].v; break;
     case 4: c->tot_iterations += 1; break;
