@@ -8,8 +8,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmcpt_hip.so")
+# The checking build: the same sources with the direct-lighting-skip check and the pure test hooks (MCPT_RING_START,
+# MCPT_HOST_DELAY_US) compiled in.  Tests load it explicitly; the product library carries neither.
+LIB_CHECK = os.path.join(HERE, "libmcpt_hip_check.so")
+CHECK_DEFINES = ["-DMCPT_TEST_HOOKS", "-DMCPT_CHECK_DIRECT_SKIP"]
 SOURCES = ["mcpt_scene.cpp", "mcpt_kernels.hip", "mcpt_api.hip"]
-HEADERS = ["mcpt_internal.h", "mcpt_device.h", "mcpt_kernels.h", os.path.join("..", "..", "include", "mcpt.h")]
+HEADERS = ["mcpt_internal.h", "mcpt_device.h", "mcpt_fmath.h", "mcpt_kernels.h", os.path.join("..", "..", "include", "mcpt.h")]
 # -ffp-contract=off: the arithmetic contract of csrc/mcpt_device.h (no FMA contraction, so the same seeds
 # give the same paths as the CPU restatement).  f32 divide/sqrt stay correctly rounded (hipcc default).
 # -fno-slp-vectorize: the SLP vectoriser pairs scalar f32 adds/muls into v_pk_*_f32, which issue slower than the two
@@ -24,30 +28,45 @@ def hipcc():
     return "hipcc"
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
-    objs = []
-    for s in SOURCES:
-        o = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
-        cmd = [hipcc()] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", o]
+def _compile(lib, defines, suffix, verbose):
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(s):
+        o = os.path.join(CSRC, os.path.splitext(s)[0] + suffix + ".o")
+        cmd = [hipcc()] + FLAGS + defines + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(o)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        return o
+
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        objs = list(ex.map(one, SOURCES))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build(LIB):
+        return LIB
+    return _compile(LIB, [], "", verbose)
+
+
+def build_check(force=False, verbose=False):
+    """libmcpt_hip_check.so (see LIB_CHECK)."""
+    if not force and not needs_build(LIB_CHECK):
+        return LIB_CHECK
+    return _compile(LIB_CHECK, CHECK_DEFINES, ".check", verbose)
 
 
 def build_host(verbose=False):
@@ -58,3 +77,4 @@ def build_host(verbose=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_check(force="--force" in sys.argv, verbose=True))

@@ -38,10 +38,15 @@ int fail(int code, const std::string &msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                             \
     } while (0)
 
+// Owning device allocation: freed by release() or when it goes out of scope, so an early error return cannot leak it.
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
     hipError_t alloc(size_t count) {
         if (count <= n && p) return hipSuccess;
         release();
@@ -110,6 +115,35 @@ struct SharedBufs {
     }
 };
 
+// Environment knobs, read ONCE per scene in mcpt_scene_create: a render call never calls getenv.
+struct Knobs {
+    bool overlap = true;        // MCPT_OVERLAP=0: one stream instead of three
+    bool queue_ahead = true;    // MCPT_QUEUE_AHEAD=0: wait for the counters before launching the chains
+    bool timing = true;         // MCPT_TIMING=0: no per-kernel HIP events
+    int pools = 1;              // MCPT_POOLS=2: two pools on two host threads
+    int drain_batch = 4;        // MCPT_DRAIN_BATCH: iterations per host sync in the drain tail
+    uint64_t pool_min_work = 1ull << 20;  // MCPT_POOL_MIN_WORK: smallest pass (samples) that uses two pools
+    uint32_t shadow_grid_per_cu = 1024;   // MCPT_SHADOW_GRID_PER_CU: grid cap of k_trace_shadow
+    // pure test hooks, compiled only into the checking build (-DMCPT_TEST_HOOKS, libmcpt_hip_check.so)
+    uint32_t ring_start = 0;    // MCPT_RING_START: the free ring's counters start here (exercises the 2^32 wrap)
+    int host_delay_us = 0;      // MCPT_HOST_DELAY_US: a slow host
+    void read() {
+        auto off = [](const char *n) { const char *v = std::getenv(n); return v && v[0] == '0'; };
+        overlap = !off("MCPT_OVERLAP");
+        queue_ahead = !off("MCPT_QUEUE_AHEAD");
+        timing = !off("MCPT_TIMING");
+        const char *v;
+        if ((v = std::getenv("MCPT_POOLS"))) pools = (v[0] == '2') ? 2 : 1;
+        if ((v = std::getenv("MCPT_DRAIN_BATCH"))) drain_batch = std::max(1, std::atoi(v));
+        if ((v = std::getenv("MCPT_POOL_MIN_WORK"))) pool_min_work = (uint64_t)std::max(1, std::atoi(v));
+        if ((v = std::getenv("MCPT_SHADOW_GRID_PER_CU"))) shadow_grid_per_cu = (uint32_t)std::max(1, std::atoi(v));
+#ifdef MCPT_TEST_HOOKS
+        if ((v = std::getenv("MCPT_RING_START"))) ring_start = (uint32_t)std::strtoul(v, nullptr, 0);
+        if ((v = std::getenv("MCPT_HOST_DELAY_US"))) host_delay_us = std::atoi(v);
+#endif
+    }
+};
+
 enum KClass { K_CLOSEST = 0, K_SHADOW, K_SHADE, K_GENERATE, K_RESOLVE, K_DIRECT, K_NCLASS };
 
 struct Timer {
@@ -174,6 +208,7 @@ struct Timer {
 
 struct mcpt_scene {
     int device = 0;
+    Knobs knobs;
     mcpt_scene_info info{};
     DevBuf<Node> nodes;
     DevBuf<QNode> qnodes;
@@ -333,8 +368,8 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     const int n_dir = C.n_dir;
     const int P = (int)plan.size();
     C.track_live = (acc && P > 1) ? 1 : 0;
-    const char *rs = std::getenv("MCPT_RING_START");  // test hook: start the ring counters near 2^32
-    launch_init_free(w.free_slots.p, w.counters.p, pool, rs ? (uint32_t)std::strtoul(rs, nullptr, 0) : 0u, w.free_ring - 1u, st);
+    const Knobs &K = sc->knobs;
+    launch_init_free(w.free_slots.p, w.counters.p, pool, K.ring_start, w.free_ring - 1u, st);
     if (ctx.side[1]) {  // fork: the side streams start after everything queued on `st` so far (counters, pixel list, framebuffer)
         HIP_TRY(hipEventRecord(ctx.book, st));
         for (int k = 0; k < 2; ++k) HIP_TRY(hipStreamWaitEvent(ctx.side[k], ctx.book, 0));
@@ -416,11 +451,9 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
         }
     }
 
-    const char *qa = std::getenv("MCPT_QUEUE_AHEAD"), *hd = std::getenv("MCPT_HOST_DELAY_US");
-    const bool queue_ahead = !(qa && qa[0] == '0');
-    const int host_delay_us = hd ? std::atoi(hd) : 0;
-    const char *db = std::getenv("MCPT_DRAIN_BATCH");  // iterations queued per host sync once no samples are left to issue
-    const int drain_batch = db ? std::max(1, std::atoi(db)) : 4;
+    const bool queue_ahead = K.queue_ahead;
+    const int host_delay_us = K.host_delay_us;
+    const int drain_batch = K.drain_batch;  // iterations queued per host sync once no samples are left to issue
     while (n_cur_max > 0 || issue_pass < P || (acc && accum_next < P)) {
         ++it;
         // (big lists keep the three-stream schedule with exact launch sizes: over-sized grids only pay off when small)
@@ -441,7 +474,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
                 T.end(ev, K_DIRECT, st);
                 if (C.enable_shadow) {
                     ev = T.begin(st);
-                    launch_trace_shadow(sc->view, w.counters.p, nxt, n_cur_max * (uint32_t)n_dir, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
+                    launch_trace_shadow(sc->view, w.counters.p, nxt, n_cur_max * (uint32_t)n_dir, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, K.shadow_grid_per_cu, st);
                     T.end(ev, K_SHADOW, st);
                 }
                 ev = T.begin(st);
@@ -519,7 +552,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             T.end(ev, K_DIRECT, st);
             if (C.enable_shadow) {
                 ev = T.begin(st);
-                launch_trace_shadow(sc->view, w.counters.p, nxt, grid_direct * (uint32_t)n_dir, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, st);
+                launch_trace_shadow(sc->view, w.counters.p, nxt, grid_direct * (uint32_t)n_dir, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, K.shadow_grid_per_cu, st);
                 T.end(ev, K_SHADOW, st);
             }
         }
@@ -560,6 +593,26 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     return MCPT_OK;
 }
 
+// After a failed run_wavefront the side streams may still hold kernels that use the workspace: wait for them before the
+// caller sees the error (and possibly frees buffers).  The error text of the failure is kept.
+int drained(int rc) {
+    if (rc != MCPT_OK) {
+        const std::string keep = g_err;
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+        g_err = keep;
+    }
+    return rc;
+}
+
+// Device bytes one pool path costs in ensure_workspace (two waves + scratch + clamp stack + free ring).
+uint64_t bytes_per_pool_path(int n_dir, int max_depth) {
+    const double rays = 1.0 + 1.0 / 3.0;
+    const double wave = 16 + 16 + rays * 48 + 4.0 * n_dir + 8.0 / 3.0;
+    const double scratch = 3 * 16 + 4 + 32.0 * n_dir;
+    return (uint64_t)(2 * wave + scratch + 16.0 * max_depth + 16.0);
+}
+
 int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, float *fb_dev, hipStream_t st,
                 mcpt_stats *stats) {
     if (!sc || !cam || !pp || !fb_dev) return fail(MCPT_ERR_ARG, "mcpt_render: null argument");
@@ -595,10 +648,23 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     // light-sample indices (record * n_dir + k) are 32-bit
     while (pool64 * (uint64_t)p.n_dir_sample > (1ull << 31) && pool64 > 3 * 4096) pool64 /= 2;
     pool64 = std::min<uint64_t>(pool64, std::max<uint64_t>(3ull * n_pix * (uint64_t)s_pass, 3 * 256));
+    // ... and the workspace within 80 % of the memory that is free now plus what the existing workspace already holds (other
+    // tenants of the GPU, a second scene): a smaller pool is slower, never wrong
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            uint64_t held = 0;
+            for (int k = 0; k < mcpt_scene::kMaxPools; ++k) held += (uint64_t)sc->pools[k].ws.pool * bytes_per_pool_path(sc->pools[k].ws.n_dir, sc->pools[k].ws.max_depth);
+            const uint64_t result_b = (uint64_t)n_pix * s_pass * 3ull * 4ull * 2ull;
+            const uint64_t have = (uint64_t)free_b + held + sc->shared.result.bytes();
+            const uint64_t budget = have * 8 / 10 > result_b ? have * 8 / 10 - result_b : 0;
+            const uint64_t per = bytes_per_pool_path(p.n_dir_sample, max_depth);
+            while (pool64 * per > budget && pool64 > 3 * 4096) pool64 /= 2;
+        }
+    }
     // two pools (each half the paths) once a pass is big enough to keep both busy
     int n_pools = sc->n_pools;
-    const char *mw = std::getenv("MCPT_POOL_MIN_WORK");  // samples per pass below which one pool is used
-    const uint64_t min_work = mw ? (uint64_t)std::max(1, std::atoi(mw)) : (1ull << 20);
+    const uint64_t min_work = sc->knobs.pool_min_work;  // samples per pass below which one pool is used
     if ((uint64_t)n_pix * s_pass < min_work || pool64 / 2 < 3 * 256) n_pools = 1;
     const uint32_t pool = (uint32_t)(pool64 / n_pools / 3 * 3);
 
@@ -631,10 +697,9 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     const CameraConst cc = make_camera(*cam);
     const float spp_total = (float)(p.spp_total > 0 ? p.spp_total : p.spp);
 
-    const char *tenv = std::getenv("MCPT_TIMING");
     for (int k = 0; k < n_pools; ++k) {
         sc->pools[k].timer.reset();
-        sc->pools[k].timer.enabled = !(tenv && tenv[0] == '0');
+        sc->pools[k].timer.enabled = sc->knobs.timing;
         sc->pools[k].pushes = sc->pools[k].overflow = 0;
     }
     LoopTotals tot[mcpt_scene::kMaxPools];
@@ -646,7 +711,7 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
             plan.push_back(PassPlan{0u, n_pix * (uint32_t)s_now, s_now, p.sample_offset + k0});
         }
         AccumPlan acc{fb_dev, spp_total, n_pix, sh.pixel_list.p, {C.result[0], C.result[1]}};
-        const int rc = run_wavefront(sc, sc->pools[0], C, &cc, plan, &acc, st, tot[0]);
+        const int rc = drained(run_wavefront(sc, sc->pools[0], C, &cc, plan, &acc, st, tot[0]));
         if (rc != MCPT_OK) return rc;
     } else {
         for (int k0 = 0; k0 < p.spp; k0 += s_pass) {
@@ -672,8 +737,8 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
             });
             const int rc0 = run_wavefront(sc, sc->pools[0], C, &cc, plan0, nullptr, st, tot[0]);
             worker.join();  // run_wavefront ends with a stream synchronise: both halves are complete here
-            if (rc0 != MCPT_OK) return rc0;
-            if (c1.rc != MCPT_OK) return fail(c1.rc, c1.err);
+            if (rc0 != MCPT_OK) return drained(rc0);
+            if (c1.rc != MCPT_OK) return drained(fail(c1.rc, c1.err));
             Timer &T0 = sc->pools[0].timer;
             int ev = T0.begin(st);
             launch_accumulate(C.result[0], sh.pixel_list.p, n_pix, s_now, spp_total, fb_dev, st);
@@ -738,7 +803,13 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
 extern "C" {
 
 const char *mcpt_last_error(void) { return g_err.c_str(); }
-const char *mcpt_version(void) { return "mcpt-hip 0.1 (gfx950)"; }
+const char *mcpt_version(void) {
+#if defined(MCPT_TEST_HOOKS) || defined(MCPT_CHECK_DIRECT_SKIP) || defined(MCPT_TRAVERSAL_STATS)
+    return "mcpt-hip 0.2 (gfx950) checking build";
+#else
+    return "mcpt-hip 0.2 (gfx950)";
+#endif
+}
 
 int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out) {
     if (!desc || !out) return fail(MCPT_ERR_ARG, "mcpt_scene_create: null argument");
@@ -761,14 +832,13 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
     if (!sc) return fail(MCPT_ERR_OOM, "mcpt_scene_create: host allocation failed");
     sc->device = device;
     hipError_t e = hipSuccess;
-    const char *ov = std::getenv("MCPT_OVERLAP");
-    const char *np = std::getenv("MCPT_POOLS");
+    sc->knobs.read();
     // One pool by default: two pools measured +1..2 % at equal total size (2772 vs 2748 Msamples/s), within noise.
-    sc->n_pools = (np && np[0] == '2') ? 2 : 1;
+    sc->n_pools = sc->knobs.pools;
     for (int q = 0; q < sc->n_pools && e == hipSuccess; ++q) {
         PoolCtx &c = sc->pools[q];
         if (q > 0) e = hipStreamCreateWithFlags(&c.main, hipStreamNonBlocking);
-        if (!(ov && ov[0] == '0')) {
+        if (sc->knobs.overlap) {
             for (int k = 0; k < 2 && e == hipSuccess; ++k) {
                 e = hipStreamCreateWithFlags(&c.side[k], hipStreamNonBlocking);
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&c.join[k], hipEventDisableTiming);
@@ -944,12 +1014,8 @@ int mcpt_render(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *p, fl
     const int rc = render_impl(sc, cam, p, fb.p, nullptr, stats);
     if (rc == MCPT_OK || rc == MCPT_ERR_OVERFLOW) {
         const hipError_t e = hipMemcpy(fb_host, fb.p, n * sizeof(float), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            fb.release();
-            return fail(MCPT_ERR_HIP, std::string("framebuffer download: ") + hipGetErrorString(e));
-        }
+        if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("framebuffer download: ") + hipGetErrorString(e));
     }
-    fb.release();
     return rc;
 }
 
@@ -971,7 +1037,6 @@ int mcpt_intersect(mcpt_scene *sc, int64_t n, const float *origins, const float 
     launch_trace_closest(sc->view, (uint32_t)n, nullptr, dO.p, dD.p, dH.p, nullptr);
     std::vector<uint4> h(n);
     const hipError_t e = hipMemcpy(h.data(), dH.p, n * sizeof(uint4), hipMemcpyDeviceToHost);
-    dO.release(); dD.release(); dH.release();
     if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("mcpt_intersect: ") + hipGetErrorString(e));
     for (int64_t i = 0; i < n; ++i) {
         const unsigned long long b = ((unsigned long long)h[i].y << 32) | h[i].x;
@@ -1034,7 +1099,7 @@ int mcpt_cast_rays(mcpt_scene *sc, const mcpt_params *pp, int64_t n, const float
         C.result[0] = C.result[1] = sh.result.p;
         LoopTotals tot;
         const std::vector<PassPlan> plan{PassPlan{0u, m, 1, 0}};
-        const int rc = run_wavefront(sc, ctx, C, nullptr, plan, nullptr, nullptr, tot);
+        const int rc = drained(run_wavefront(sc, ctx, C, nullptr, plan, nullptr, nullptr, tot));
         if (rc != MCPT_OK) return rc;
         HIP_TRY(hipMemcpy(out + base, sh.result.p, m * sizeof(float), hipMemcpyDeviceToHost));
     }
@@ -1059,12 +1124,40 @@ int mcpt_camera_rays(mcpt_scene *sc, const mcpt_camera *cam, uint32_t seed, int6
     std::vector<float4> o(n), d(n);
     hipError_t e = hipMemcpy(o.data(), dO.p, n * sizeof(float4), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(d.data(), dD.p, n * sizeof(float4), hipMemcpyDeviceToHost);
-    dP.release(); dS.release(); dO.release(); dD.release();
     if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("mcpt_camera_rays: ") + hipGetErrorString(e));
     for (int64_t i = 0; i < n; ++i) {
         origins[3 * i] = o[i].x; origins[3 * i + 1] = o[i].y; origins[3 * i + 2] = o[i].z;
         dirs[3 * i] = d[i].x; dirs[3 * i + 1] = d[i].y; dirs[3 * i + 2] = d[i].z;
     }
+    return MCPT_OK;
+}
+
+int mcpt_debug_counters(mcpt_scene *sc, uint64_t out[16]) {
+    if (!sc || !out) return fail(MCPT_ERR_ARG, "mcpt_debug_counters: null argument");
+    std::memset(out, 0, 16 * sizeof(uint64_t));
+    if (!sc->dbg.p) return MCPT_OK;  // a product build: nothing is counted
+    HIP_TRY(hipSetDevice(sc->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long h[16];
+    HIP_TRY(hipMemcpy(h, sc->dbg.p, sizeof h, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 16; ++k) out[k] = h[k];
+    return MCPT_OK;
+}
+
+int mcpt_debug_fmath(mcpt_scene *sc, int kind, int64_t n, const float *x, const float *y, float *out) {
+    if (!sc || kind < 0 || kind > 3 || n < 0 || (n > 0 && (!x || !out || (kind == 2 && !y)))) return fail(MCPT_ERR_ARG, "mcpt_debug_fmath: bad argument");
+    if (n == 0) return MCPT_OK;
+    if (n > 0x7fffffff) return fail(MCPT_ERR_ARG, "mcpt_debug_fmath: too many values for one call");
+    HIP_TRY(hipSetDevice(sc->device));
+    DevBuf<float> dX, dY, dO;
+    HIP_TRY(dX.alloc(n));
+    HIP_TRY(dY.alloc(n));
+    HIP_TRY(dO.alloc(n));
+    HIP_TRY(hipMemcpy(dX.p, x, n * sizeof(float), hipMemcpyHostToDevice));
+    if (y) HIP_TRY(hipMemcpy(dY.p, y, n * sizeof(float), hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemset(dY.p, 0, n * sizeof(float)));
+    launch_debug_fmath(kind, (uint32_t)n, dX.p, dY.p, dO.p, nullptr);
+    HIP_TRY(hipMemcpy(out, dO.p, n * sizeof(float), hipMemcpyDeviceToHost));
     return MCPT_OK;
 }
 

@@ -4,10 +4,12 @@
 // precision class -- float vectors with Eigen's 3-term dot order x0*y0 + (x1*y1 + x2*y2), the double
 // det/u/v/t chain of Triangle::getIntersection, double sub-expressions wherever the reference source has a
 // double literal -- and the file is compiled with -ffp-contract=off, so that the same seeds give the
-// same paths as the CPU restatement except where libm (sinf/cosf) rounding flips a branch.
+// same paths as a CPU restatement that follows the same contract.  sin/cos/atan2/acos come from mcpt_fmath.h (plain IEEE
+// arithmetic, identical on host and device), not from the device libm.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "mcpt_fmath.h"
 #include "mcpt_internal.h"
 
 namespace mcpt {
@@ -293,7 +295,9 @@ MCPT_DI f3 importance_sample_ggx(float xi_x, float xi_y, float alpha, f3 n) {  /
     const float phi = 2.0f * kPi * xi_x;
     const float cosTheta = sqrtf((1.0f - xi_y) / (1.0f + (alpha * alpha - 1.0f) * xi_y));
     const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
-    const f3 h = mk3(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+    float sp, cp;
+    mcpt_sincosf(phi, &sp, &cp);  // std::cos / std::sin, Material.hpp:117-118
+    const f3 h = mk3(sinTheta * cp, sinTheta * sp, cosTheta);
     return normalized(tan_to_world(h, n));
 }
 
@@ -412,8 +416,8 @@ MCPT_DI float mat_eval(const MaterialRec &m, f3 wi, f3 wo, f3 N, int ch, f2 uv, 
 MCPT_DI f3 sample_env(const DevScene &S, f3 dir) {
     if (S.env_w <= 0) return mk3(S.background[0], S.background[1], S.background[2]);
     const f3 d = normalized(dir);
-    const float phi = atan2f(d.z, d.x);
-    const float theta = acosf(d.y);
+    const float phi = mcpt_atan2f(d.z, d.x);  // Scene.hpp:66-67
+    const float theta = mcpt_acosf(d.y);
     float u = (phi + kPi) / (2.f * kPi);
     float v = theta / kPi;
     u = u - floorf(u);

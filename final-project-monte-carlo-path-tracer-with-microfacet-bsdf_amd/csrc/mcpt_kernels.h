@@ -114,10 +114,11 @@ void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X
 // Shadow queue (lengths in counters->n_shadow / n_shadow_w, together at most n_max; arrays of `cap` entries): zeroes
 // contrib[] of invisible samples.
 void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, uint32_t cap, Scratch X,
-                         float *contrib, hipStream_t s);
+                         float *contrib, uint32_t grid_per_cu, hipStream_t s);
 // Shades list `cur_idx` (at most n_cur_max records; the true count is read from the device counter) into the other list.
 void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, Scratch X, int cur_idx, uint32_t n_cur_max,
                   hipStream_t s);
+void launch_debug_fmath(int kind, uint32_t n, const float *x, const float *y, float *out, hipStream_t s);
 void launch_accumulate(const float *result, const uint32_t *pixel_list, uint32_t n_pix, int32_t s_pass, float spp_total,
                        float *fb, hipStream_t s);
 

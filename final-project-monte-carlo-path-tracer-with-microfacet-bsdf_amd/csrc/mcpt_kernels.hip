@@ -375,8 +375,10 @@ MCPT_DI void camera_ray(const CameraConst &cam, uint32_t seed, uint32_t m, uint3
         const f3 focal_point = mk3(x, y, 1) * cam.focal_distance;
         const float r = cam.aperture_radius * sqrtf(u[2]);
         const float theta = 2 * kPi * u[3];
-        const float dx = r * cosf(theta);
-        const float dy = r * sinf(theta);
+        float st, ct;
+        mcpt_sincosf(theta, &st, &ct);  // Renderer.cpp:59-60
+        const float dx = r * ct;
+        const float dy = r * st;
         pos = eye + mat3_mul(cam.orient, mk3(dx, dy, 0));
         dir = normalized(focal_point - mk3(dx, dy, 0));
     } else {
@@ -537,7 +539,10 @@ MCPT_DI bool sample_light(const DevScene &S, const float u[4], f3 &x_l, f3 &n_l,
             } else {  // Sphere::Sample, Sphere.hpp:64-74 (leaves pos.emit untouched: zero here)
                 const SphereRec s = S.spheres[L.root];
                 const float theta = (float)(2.0 * (double)kPi * (double)u[2]), phi = kPi * u[3];
-                const f3 dir = mk3(cosf(phi), sinf(phi) * cosf(theta), sinf(phi) * sinf(theta));
+                float sph, cph, sth, cth;
+                mcpt_sincosf(phi, &sph, &cph);
+                mcpt_sincosf(theta, &sth, &cth);
+                const f3 dir = mk3(cph, sph * cth, sph * sth);
                 x_l = mk3(s.c[0], s.c[1], s.c[2]) + dir * s.radius;
                 n_l = dir;
                 prim = S.n_tri + L.root;
@@ -945,6 +950,18 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float *__restrict__
     fb[(size_t)m * 3 + c] = acc;
 }
 
+__global__ __launch_bounds__(kBlock) void k_debug_fmath(int kind, uint32_t n, const float *x, const float *y, float *out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float s, c;
+    switch (kind) {
+    case 0: mcpt_sincosf(x[i], &s, &c); out[i] = s; break;
+    case 1: mcpt_sincosf(x[i], &s, &c); out[i] = c; break;
+    case 2: out[i] = mcpt_atan2f(x[i], y[i]); break;
+    default: out[i] = mcpt_acosf(x[i]); break;
+    }
+}
+
 inline uint32_t blocks(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 }  // namespace
@@ -1036,14 +1053,12 @@ void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X
 }
 
 void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, uint32_t cap, Scratch X,
-                         float *contrib, hipStream_t s) {
+                         float *contrib, uint32_t per_cu, hipStream_t s) {
     if (n_max == 0) return;
     // The queue length is only known on the device.  The grid covers the upper bound (capped at 1024 workgroups per
     // CU, far more than are resident, so the hardware balances uneven rays dynamically: a persistent 8-per-CU grid
     // was 30 % slower on the Cornell box); workgroups past the end of the queue exit at once, longer queues stride.
     const int stk = S.height <= 16 ? 16 : (S.height <= 20 ? 20 : (S.height <= 24 ? 24 : (S.height <= 32 ? 32 : kMaxBvhHeight)));
-    const char *cap_env = std::getenv("MCPT_SHADOW_GRID_PER_CU");
-    const uint32_t per_cu = cap_env ? (uint32_t)std::max(1, std::atoi(cap_env)) : 1024u;
     const dim3 g(std::min<uint32_t>(blocks(n_max), 256u * per_cu)), b(kBlock);
     if (stk == 16) hipLaunchKernelGGL((k_trace_shadow<16>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
     else if (stk == 20) hipLaunchKernelGGL((k_trace_shadow<20>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
@@ -1056,6 +1071,11 @@ void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, 
                   hipStream_t s) {
     if (n_cur_max == 0) return;
     hipLaunchKernelGGL(k_shade, dim3((n_cur_max + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, s, S, C, cur, next, X, cur_idx);
+}
+
+void launch_debug_fmath(int kind, uint32_t n, const float *x, const float *y, float *out, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_debug_fmath, dim3(blocks(n)), dim3(kBlock), 0, s, kind, n, x, y, out);
 }
 
 void launch_accumulate(const float *result, const uint32_t *pixel_list, uint32_t n_pix, int32_t s_pass, float spp_total,

@@ -13,9 +13,11 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCPT_LIB") or os.path.join(HERE, "libmcpt_hip.so")  # MCPT_LIB: diagnostic builds only
+CHECK_LIB_PATH = os.path.join(HERE, "libmcpt_hip_check.so")  # the checking build (build.build_check); tests only
 
 EXPORTS = ["mcpt_scene_create", "mcpt_scene_destroy", "mcpt_render", "mcpt_render_device", "mcpt_intersect",
-           "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_bvh_dump", "mcpt_last_error", "mcpt_version"]
+           "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_bvh_dump", "mcpt_debug_fmath", "mcpt_debug_counters",
+           "mcpt_last_error", "mcpt_version"]
 
 
 class McptError(RuntimeError):
@@ -55,16 +57,16 @@ class SceneInfo(C.Structure):
                 ("scene_bytes", C.c_uint64)]
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    """Loads libmcpt_hip.so; raises if it has not been built (run __graft_entry__.build())."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise FileNotFoundError("%s is missing: build it with `python __graft_entry__.py` (hipcc, gfx950)" % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
+def lib(path=None):
+    """Loads libmcpt_hip.so (or the library at `path`); raises if it has not been built (run __graft_entry__.build())."""
+    path = path or LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise FileNotFoundError("%s is missing: build it with `python __graft_entry__.py` (hipcc, gfx950)" % path)
+        L = C.CDLL(path)
         L.mcpt_last_error.restype = C.c_char_p
         L.mcpt_version.restype = C.c_char_p
         L.mcpt_scene_create.restype = C.c_int
@@ -85,13 +87,17 @@ def lib():
         L.mcpt_cast_rays.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int64] + [C.c_void_p] * 6
         L.mcpt_camera_rays.restype = C.c_int
         L.mcpt_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64] + [C.c_void_p] * 4
-        _lib = L
-    return _lib
+        L.mcpt_debug_fmath.restype = C.c_int
+        L.mcpt_debug_fmath.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcpt_debug_counters.restype = C.c_int
+        L.mcpt_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
+        _libs[path] = L
+    return _libs[path]
 
 
-def _check(rc, allow=()):
+def _check(rc, allow=(), L=None):
     if rc != 0 and rc not in allow:
-        raise McptError(rc, lib().mcpt_last_error().decode("utf-8", "replace"))
+        raise McptError(rc, (L or lib()).mcpt_last_error().decode("utf-8", "replace"))
     return rc
 
 
@@ -138,19 +144,26 @@ def bvh_dump(sd):
 class HipScene:
     """A scene resident in the HBM of one GPU (mcpt_scene_create)."""
 
-    def __init__(self, sd, device=-1):
+    def __init__(self, sd, device=-1, library=None):
+        """library: path of an alternative build of the same ABI (the checking build); None = the product library."""
         self.sd = sd
         self._keep = []
+        self.L = lib(library)
         d = _make_desc(sd, self._keep)
         h = C.c_void_p()
         self.h = None
-        _check(lib().mcpt_scene_create(C.byref(d), int(device), C.byref(h)))
+        _check(self.L.mcpt_scene_create(C.byref(d), int(device), C.byref(h)), L=self.L)
         self.h = h
 
     def close(self):
         if getattr(self, "h", None):
-            lib().mcpt_scene_destroy(self.h)
+            self.L.mcpt_scene_destroy(self.h)
             self.h = None
+
+    def debug_counters(self):
+        out = np.zeros(16, dtype=np.uint64)
+        _check(self.L.mcpt_debug_counters(self.h, _ptr(out)), L=self.L)
+        return out
 
     def __del__(self):
         try:
@@ -160,7 +173,7 @@ class HipScene:
 
     def info(self):
         i = SceneInfo()
-        _check(lib().mcpt_scene_get_info(self.h, C.byref(i)))
+        _check(self.L.mcpt_scene_get_info(self.h, C.byref(i)), L=self.L)
         return {k: getattr(i, k) for k, _ in i._fields_}
 
     def params(self, spp=None, seed=1, spp_total=0, sample_offset=0, accumulate=0, tile_size=32, rank=0, nranks=1,
@@ -180,7 +193,7 @@ class HipScene:
             fb = np.zeros((H, W, 3), dtype=np.float32)
         p = self.params(**kw)
         st = Stats()
-        _check(lib().mcpt_render(self.h, _ptr(cam), C.byref(p), _ptr(fb), C.byref(st)))
+        _check(self.L.mcpt_render(self.h, _ptr(cam), C.byref(p), _ptr(fb), C.byref(st)), L=self.L)
         return fb, st
 
     def render_device(self, fb_ptr, stream_ptr=0, camera=None, **kw):
@@ -188,8 +201,8 @@ class HipScene:
         cam = np.ascontiguousarray(camera if camera is not None else self.sd.camera)
         p = self.params(**kw)
         st = Stats()
-        _check(lib().mcpt_render_device(self.h, _ptr(cam), C.byref(p), C.c_void_p(int(fb_ptr)), C.c_void_p(int(stream_ptr)),
-                                        C.byref(st)))
+        _check(self.L.mcpt_render_device(self.h, _ptr(cam), C.byref(p), C.c_void_p(int(fb_ptr)), C.c_void_p(int(stream_ptr)),
+                                         C.byref(st)), L=self.L)
         return st
 
     def intersect(self, origins, dirs):
@@ -198,7 +211,7 @@ class HipScene:
         n = len(o)
         t = np.zeros(n, dtype=np.float64)
         prim = np.zeros(n, dtype=np.int32)
-        _check(lib().mcpt_intersect(self.h, n, _ptr(o), _ptr(d), _ptr(t), _ptr(prim)))
+        _check(self.L.mcpt_intersect(self.h, n, _ptr(o), _ptr(d), _ptr(t), _ptr(prim)), L=self.L)
         return t, prim
 
     def cast_rays(self, origins, dirs, pixel, sample, channel, **kw):
@@ -210,7 +223,7 @@ class HipScene:
         ch = np.ascontiguousarray(channel, dtype=np.int32)
         out = np.zeros(n, dtype=np.float32)
         p = self.params(**kw)
-        _check(lib().mcpt_cast_rays(self.h, C.byref(p), n, _ptr(o), _ptr(d), _ptr(px), _ptr(sm), _ptr(ch), _ptr(out)))
+        _check(self.L.mcpt_cast_rays(self.h, C.byref(p), n, _ptr(o), _ptr(d), _ptr(px), _ptr(sm), _ptr(ch), _ptr(out)), L=self.L)
         return out
 
     def camera_rays(self, pixels, samples, seed=1, camera=None):
@@ -220,5 +233,22 @@ class HipScene:
         n = len(px)
         o = np.zeros((n, 3), dtype=np.float32)
         d = np.zeros((n, 3), dtype=np.float32)
-        _check(lib().mcpt_camera_rays(self.h, _ptr(cam), int(seed), n, _ptr(px), _ptr(sm), _ptr(o), _ptr(d)))
+        _check(self.L.mcpt_camera_rays(self.h, _ptr(cam), int(seed), n, _ptr(px), _ptr(sm), _ptr(o), _ptr(d)), L=self.L)
         return o, d
+
+
+_FMATH_SCENE = None
+
+
+def debug_fmath(kind, x, y=None):
+    """csrc/mcpt_fmath.h evaluated on the device (mcpt_debug_fmath): kind "sin" | "cos" | "atan2" | "acos"."""
+    global _FMATH_SCENE
+    if _FMATH_SCENE is None:
+        from . import scenes
+        _FMATH_SCENE = HipScene(scenes.cornell_rc(8, 8, 1))
+    k = {"sin": 0, "cos": 1, "atan2": 2, "acos": 3}[kind]
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float32)
+    out = np.zeros_like(x)
+    _check(lib().mcpt_debug_fmath(_FMATH_SCENE.h, k, x.size, _ptr(x), _ptr(y), _ptr(out)))
+    return out

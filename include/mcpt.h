@@ -174,6 +174,20 @@ typedef struct {
 } mcpt_bvh_info;
 int mcpt_bvh_dump(const mcpt_scene_desc *desc, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes);
 
+/* Diagnostic: evaluates the path's transcendental functions (csrc/mcpt_fmath.h: the library's own plain-IEEE sin / cos /
+ * atan2 / acos, used where the reference calls libm at Material.hpp:117-118, Renderer.cpp:59-60, Sphere.hpp:66-67,
+ * Scene.hpp:66-67) ON THE DEVICE for n host floats, so that tests can check that kernels and a CPU build of the same
+ * header agree bit for bit.  kind: 0 sin(x), 1 cos(x), 2 atan2(x, y), 3 acos(x); y may be NULL unless kind == 2. */
+int mcpt_debug_fmath(mcpt_scene *scene, int kind, int64_t n, const float *x, const float *y, float *out);
+
+/* Diagnostic: counters of the checking build (libmcpt_hip_check.so, compiled with -DMCPT_CHECK_DIRECT_SKIP; the traversal
+ * entries are filled only by a -DMCPT_TRAVERSAL_STATS build); all zero in the product build.
+ *   out[0..5]   closest-hit rays: rays, node visits, primitive tests, hits, 64 x wave iterations, -
+ *   out[8..13]  shadow rays: rays, node visits, primitive tests, occluded, 64 x wave iterations, found in the window
+ *   out[14]     light samples evaluated at vertices the product would have skipped as "provably zero" (direct_is_zero)
+ *   out[15]     how many of those had a non-zero contribution (must be 0) */
+int mcpt_debug_counters(mcpt_scene *scene, uint64_t out[16]);
+
 const char *mcpt_last_error(void);
 const char *mcpt_version(void);
 

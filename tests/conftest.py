@@ -32,3 +32,26 @@ def hip(pkg):
     pkg.build.build()
     pkg.hip_backend.lib()
     return pkg.hip_backend
+
+
+@pytest.fixture(scope="session")
+def hip_check(pkg, hip):
+    """Path of the checking build of the same ABI (libmcpt_hip_check.so: -DMCPT_CHECK_DIRECT_SKIP -DMCPT_TEST_HOOKS)."""
+    path = pkg.build.build_check()
+    hip.lib(path)
+    return path
+
+
+TREES = [("sah", None), ("sah", "0"), ("reference", "0"), ("reference", "1")]  # MCPT_BVH x MCPT_QUANT_NODES (None = automatic)
+
+
+@pytest.fixture
+def tree_env(monkeypatch):
+    """Selects the traversal tree of scenes created afterwards: (MCPT_BVH, MCPT_QUANT_NODES)."""
+    def set_tree(bvh, quant):
+        monkeypatch.setenv("MCPT_BVH", bvh)
+        if quant is None:
+            monkeypatch.delenv("MCPT_QUANT_NODES", raising=False)
+        else:
+            monkeypatch.setenv("MCPT_QUANT_NODES", quant)
+    return set_tree

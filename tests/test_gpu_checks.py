@@ -1,0 +1,67 @@
+"""The checking build (libmcpt_hip_check.so, -DMCPT_CHECK_DIRECT_SKIP): every vertex whose direct lighting the product skips
+as "provably zero" (direct_is_zero in csrc/mcpt_kernels.hip: no emitter / conductor seen from inside / Dirac BSDF whose mirror or
+Snell direction misses the cone of the emitters' bounding sphere) is evaluated anyway, and a non-zero light sample among them
+is counted.  The count must be 0 on the three shipped scenes and on a scene built to sit on the rule's edges
+(Material.hpp:379-403: a Dirac eval is non-zero only within acos(1 - 1e-4) of the mirror / Snell direction)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _quad(pkg, a, b, c, d):
+    t = np.zeros(2, pkg.scenes.TRI_DTYPE)
+    t["v0"], t["v1"], t["v2"] = [a, a], [b, c], [c, d]
+    return t
+
+
+def adversarial_scene(pkg, w=96, h=64):
+    """A 1 x 1 area light (bounding-sphere radius R = 0.708) with Dirac surfaces from just outside the rule's distance gate
+    (D > 1.01 R) outwards: a mirror 0.73 below the light centre (D/R from 1.03 at its middle), a tilted mirror whose reflections
+    of the camera rays sweep across the light's rim, a glass sphere almost touching the light, a glass slab under it (refraction
+    from inside, the 0.15 rad rule), and a rough floor that sends paths everywhere else."""
+    s = pkg.scenes
+    P = s.material_presets()
+    b = s._Builder()
+    light = s._mat(s.ROUGH_CONDUCTOR, emission=(40, 35, 30))
+    y = 2.0
+    b.add_mesh(_quad(pkg, (-0.5, y, -0.5), (0.5, y, -0.5), (0.5, y, 0.5), (-0.5, y, 0.5)), b.material("light", light))
+    b.add_mesh(_quad(pkg, (-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6)), b.material("rough_white_conductor", P["rough_white_conductor"]))
+    ym = y - 0.73
+    b.add_mesh(_quad(pkg, (-0.4, ym, -0.4), (-0.4, ym, 0.4), (0.4, ym, 0.4), (0.4, ym, -0.4)), b.material("silver_mirror", P["silver_mirror"]))
+    b.add_mesh(_quad(pkg, (1.0, 0.2, -1.0), (1.0, 0.2, 1.0), (2.2, 1.6, 1.0), (2.2, 1.6, -1.0)), b.material("gold_conductor", P["gold_conductor"]))
+    b.add_sphere((-1.05, 1.9, 0.0), 0.5, b.material("smooth_glass", P["smooth_glass"]))
+    b.add_sphere((0.0, 0.45, 1.2), 0.45, b.material("smooth_glass_gem", P["smooth_glass_gem"]))
+    g0, g1 = 0.9, 1.1  # glass slab (two faces) between the floor and the light
+    b.add_mesh(np.concatenate([_quad(pkg, (-0.8, g1, -0.8), (-0.8, g1, 0.8), (0.8, g1, 0.8), (0.8, g1, -0.8)),
+                               _quad(pkg, (-0.8, g0, -0.8), (0.8, g0, -0.8), (0.8, g0, 0.8), (-0.8, g0, 0.8))]),
+               b.material("smooth_glass", P["smooth_glass"]))
+    cam = s.make_camera(w, h, 55, (0.3, 1.3, -4.5), (0.2, 1.1, 0.0))
+    return s.SceneData(triangles=np.concatenate(b.tris).astype(s.TRI_DTYPE), materials=np.stack(b.mats).astype(s.MAT_DTYPE),
+                       objects=np.stack(b.objs).astype(s.OBJ_DTYPE), background=np.float32([0.05, 0.05, 0.08]), camera=cam,
+                       rr_rate=0.8, spp=16, name="adversarial")
+
+
+@pytest.mark.parametrize("name", ["cornell_demo", "cornell_rc", "chess", "adversarial"])
+def test_skipped_direct_lighting_is_exactly_zero(pkg, hip, hip_check, oracle, name):
+    sd = {"cornell_demo": lambda: pkg.scenes.cornell_demo(128, 128, 16), "cornell_rc": lambda: pkg.scenes.cornell_rc(96, 96, 8),
+          "chess": lambda: pkg.scenes.chess_scene(width=320, height=180, spp=16), "adversarial": lambda: adversarial_scene(pkg)}[name]()
+    spp = 32 if name == "adversarial" else int(sd.spp)
+    hc = hip.HipScene(sd, library=hip_check)
+    assert b"checking build" in hc.L.mcpt_version()
+    fb_check, st_check = hc.render(spp=spp, seed=3)
+    c = hc.debug_counters()
+    skipped, nonzero = int(c[14]), int(c[15])
+    print("\n[direct-skip check] %s: %d light samples at skipped vertices, %d non-zero" % (name, skipped, nonzero))
+    assert nonzero == 0
+    if name != "cornell_rc":  # (rough conductors only, never seen from inside: nothing is skipped there)
+        assert skipped > 1000
+    # the product build skips those vertices and renders the same frame
+    fb, st = hip.HipScene(sd).render(spp=spp, seed=3)
+    assert np.array_equal(fb, fb_check, equal_nan=True)
+    assert st.direct_vertices < st_check.direct_vertices or skipped == 0
+    assert hip.HipScene(sd).debug_counters().sum() == 0  # the product build counts nothing
+    if name == "adversarial":  # and the scene itself is rendered correctly
+        ref, _ = oracle.OracleScene(sd).render(spp=8, seed=3)
+        gpu, _ = hip.HipScene(sd).render(spp=8, seed=3)
+        assert pkg.pngio.psnr_u8(pkg.pngio.tonemap_u8(ref), pkg.pngio.tonemap_u8(gpu)) >= 60.0

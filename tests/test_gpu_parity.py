@@ -1,17 +1,30 @@
 """GPU parity tests proper: every call goes through the C ABI (include/mcpt.h) of libmcpt_hip.so and is
 checked against the CPU oracle on the same seeded inputs.
 
-Tolerances (north_star: PSNR >= 40 dB vs the CPU reference, RNG seeded identically):
-  * mcpt_intersect .... bit-exact hit distance (double) and primitive id
-  * mcpt_camera_rays .. |diff| <= 2e-6 relative (device sinf/cosf vs glibc; only the DOF lens sample uses them)
-  * mcpt_cast_rays .... >= 99 % of paths within 1e-4 relative/absolute; the rest are paths whose branch decisions
-                        were flipped by a last-bit libm difference
-  * mcpt_render ....... PSNR >= 40 dB on the 8-bit gamma-0.45 image (Renderer.cpp:95-103)
+Tolerances (north_star: PSNR >= 40 dB vs the CPU reference, RNG seeded identically).  Since kernels and oracle share one
+plain-IEEE implementation of sin/cos/atan2/acos (csrc/mcpt_fmath.h) and both are compiled without FMA contraction, the
+bar is much tighter than the north star's:
+  * mcpt_intersect .... bit-exact hit distance (double) and primitive id, under every tree (SAH / reference topology,
+                        float / quantised nodes)
+  * mcpt_camera_rays .. bit-exact
+  * mcpt_cast_rays .... with the reference's tree topology (MCPT_BVH=reference, float nodes) EVERY path value is bit-identical
+                        to the oracle's.  With the default SAH tree a ray that grazes a box face within float rounding can
+                        take a different branch (the reference's own box test is decided by rounding there); the test prints
+                        the number of such paths and allows at most 1 in 10 000.
+  * mcpt_render ....... reference tree: the float framebuffer is bit-identical; default tree: PSNR >= 60 dB on the 8-bit
+                        gamma-0.45 image (Renderer.cpp:95-103)
 """
 import numpy as np
 import pytest
+from conftest import TREES
 
 pytestmark = pytest.mark.gpu
+
+
+def _same_bits(a, b):
+    """Element-wise: identical float32 bit patterns, or both NaN."""
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
 
 
 def _scene_rays(orc_scene, sd, n, seed):
@@ -30,9 +43,11 @@ def _scene_rays(orc_scene, sd, n, seed):
     return np.concatenate([o, o2]), np.concatenate([d, d2.astype(np.float32)])
 
 
+@pytest.mark.parametrize("tree", TREES, ids=lambda t: "%s-q%s" % (t[0], t[1] or "auto"))
 @pytest.mark.parametrize("name", ["cornell_demo", "chess"])
-def test_intersect_bit_exact(pkg, oracle, hip, name):
+def test_intersect_bit_exact(pkg, oracle, hip, name, tree, tree_env):
     sd = pkg.scenes.cornell_demo(64, 64, 4) if name == "cornell_demo" else pkg.scenes.chess_scene(width=160, height=90, spp=4)
+    tree_env(*tree)
     os_, hs = oracle.OracleScene(sd), hip.HipScene(sd)
     o, d = _scene_rays(os_, sd, 20000, 11)
     t_ref, p_ref = os_.intersect(o, d)
@@ -42,11 +57,13 @@ def test_intersect_bit_exact(pkg, oracle, hip, name):
     assert (p_ref >= 0).mean() > 0.3
 
 
-def test_intersect_degenerate_directions(pkg, oracle, hip):
+@pytest.mark.parametrize("tree", [("sah", None), ("reference", "0")], ids=["sah", "reference"])
+def test_intersect_degenerate_directions(pkg, oracle, hip, tree, tree_env):
     """Axis-aligned, zero-component and all-zero directions (Material::refract returns (0,0,0) on total internal
     reflection): the reciprocals are +-inf and the slab test meets inf/NaN.  Bounds3::IntersectP's NaN behaviour
     (fmin/fmax ignore NaN, std::max({..}) keeps a NaN in the x slot) must be reproduced bit for bit."""
     sd = pkg.scenes.cornell_demo(64, 64, 4)
+    tree_env(*tree)
     os_, hs = oracle.OracleScene(sd), hip.HipScene(sd)
     rng = np.random.default_rng(5)
     n = 6000
@@ -76,15 +93,15 @@ def test_camera_rays(pkg, oracle, hip):
     smp = rng.integers(0, 2048, size=5000).astype(np.uint32)
     o_ref, d_ref = os_.camera_rays(pix, smp, seed=5)
     o_gpu, d_gpu = hs.camera_rays(pix, smp, seed=5)
-    assert np.allclose(o_ref, o_gpu, rtol=2e-6, atol=2e-5)
-    assert np.allclose(d_ref, d_gpu, rtol=2e-6, atol=2e-6)
+    assert _same_bits(o_ref, o_gpu).all() and _same_bits(d_ref, d_gpu).all()  # the lens sample's sin/cos included
 
 
 @pytest.mark.parametrize("name", ["cornell_demo", "cornell_rc", "chess"])
-def test_cast_rays_parity(pkg, oracle, hip, name):
+def test_cast_rays_parity(pkg, oracle, hip, name, tree_env, capsys):
+    """Scene::castRay per path: bit-identical with the reference's tree; mismatches under the SAH tree are counted and bounded."""
     sd = {"cornell_demo": lambda: pkg.scenes.cornell_demo(64, 64, 4), "cornell_rc": lambda: pkg.scenes.cornell_rc(64, 64, 4),
           "chess": lambda: pkg.scenes.chess_scene(width=160, height=90, spp=4)}[name]()
-    os_, hs = oracle.OracleScene(sd), hip.HipScene(sd)
+    os_ = oracle.OracleScene(sd)
     rng = np.random.default_rng(17)
     W, H = int(sd.camera["width"]), int(sd.camera["height"])
     n = 30000
@@ -93,26 +110,46 @@ def test_cast_rays_parity(pkg, oracle, hip, name):
     ch = rng.integers(0, 3, size=n).astype(np.int32)
     o, d = os_.camera_rays(pix, smp, seed=9)
     ref = os_.cast_rays(o, d, pix, smp, ch, seed=9)
-    gpu = hs.cast_rays(o, d, pix, smp, ch, seed=9)
-    both_nan = np.isnan(ref) & np.isnan(gpu)
-    close = both_nan | (np.abs(ref - gpu) <= 1e-4 * np.maximum(1.0, np.abs(ref)))
-    frac = close.mean()
-    assert frac >= 0.99, "only %.4f of the paths agree" % frac
-    assert abs(np.nanmean(ref) - np.nanmean(gpu)) <= 0.01 * max(1e-3, abs(np.nanmean(ref)))
+    tree_env("reference", "0")
+    exact = hip.HipScene(sd).cast_rays(o, d, pix, smp, ch, seed=9)
+    bad = ~_same_bits(ref, exact)
+    assert not bad.any(), "reference tree: %d of %d paths differ, e.g. %s vs %s" % (bad.sum(), n, ref[bad][:4], exact[bad][:4])
+    for tree in [("sah", None), ("sah", "0"), ("reference", "1")]:
+        tree_env(*tree)
+        gpu = hip.HipScene(sd).cast_rays(o, d, pix, smp, ch, seed=9)
+        bad = ~_same_bits(ref, gpu)
+        with capsys.disabled():
+            print("\n[parity] %s, tree %s/q%s: %d of %d paths differ from the oracle (box-grazing rays)" % (name, tree[0], tree[1] or "auto", bad.sum(), n))
+        assert bad.sum() <= max(3, n // 10000), (tree, int(bad.sum()))
+    assert np.isfinite(ref).mean() > 0.99
 
 
-def _psnr_case(pkg, oracle, hip, sd, spp, **kw):
+MIN_PSNR = 60.0  # default (SAH) tree; the north star asks for 40
+
+
+def _psnr_case(pkg, oracle, hip, sd, spp, n_dir=None, **kw):
     os_, hs = oracle.OracleScene(sd), hip.HipScene(sd)
-    fb_ref, st_ref = os_.render(spp=spp, seed=1)
-    fb_gpu, st_gpu = hs.render(spp=spp, seed=1, **kw)
+    fb_ref, st_ref = os_.render(spp=spp, seed=1, n_dir_sample=n_dir)
+    fb_gpu, st_gpu = hs.render(spp=spp, seed=1, n_dir_sample=n_dir, **kw)
     a, b = pkg.pngio.tonemap_u8(fb_ref), pkg.pngio.tonemap_u8(fb_gpu)
     return pkg.pngio.psnr_u8(a, b), st_ref, st_gpu, fb_ref, fb_gpu
+
+
+@pytest.mark.parametrize("name", ["cornell_demo", "chess"])
+def test_render_is_bit_identical_with_the_reference_tree(pkg, oracle, hip, name, tree_env):
+    """Renderer::Render end to end: same Philox keys, same arithmetic, same accumulation order => the same float frame."""
+    sd = pkg.scenes.cornell_demo(96, 96, 8) if name == "cornell_demo" else pkg.scenes.chess_scene(width=240, height=135, spp=8)
+    tree_env("reference", "0")
+    psnr, st_ref, st_gpu, fb_ref, fb_gpu = _psnr_case(pkg, oracle, hip, sd, 8, spp_per_pass=3)
+    bad = ~_same_bits(fb_ref, fb_gpu)
+    assert not bad.any(), "%d of %d framebuffer values differ" % (bad.sum(), bad.size)
+    assert st_gpu.vertices == st_ref.vertices and st_gpu.ref_scene_rays == st_ref.scene_rays
 
 
 def test_render_psnr_cornell_demo(pkg, oracle, hip):
     sd = pkg.scenes.cornell_demo(96, 96, 16)
     psnr, st_ref, st_gpu, fb_ref, fb_gpu = _psnr_case(pkg, oracle, hip, sd, 16)
-    assert psnr >= 40.0, "PSNR %.2f dB" % psnr
+    assert psnr >= MIN_PSNR, "PSNR %.2f dB" % psnr
     # the library's reference-equivalent work counters must match the oracle's call counts
     assert st_gpu.samples == st_ref.samples
     assert abs(st_gpu.vertices - st_ref.vertices) <= 0.002 * st_ref.vertices
@@ -123,14 +160,27 @@ def test_render_psnr_cornell_rc_multipass(pkg, oracle, hip):
     sd = pkg.scenes.cornell_rc(96, 96, 16)
     # small pool + several passes: exercises regeneration, compaction and pass-wise accumulation
     psnr, *_ = _psnr_case(pkg, oracle, hip, sd, 12, spp_per_pass=5, pool_paths=3 * 4096)
-    assert psnr >= 40.0, "PSNR %.2f dB" % psnr
+    assert psnr >= MIN_PSNR, "PSNR %.2f dB" % psnr
 
 
 def test_render_psnr_chess(pkg, oracle, hip):
     sd = pkg.scenes.chess_scene(width=240, height=135, spp=8)
     psnr, st_ref, st_gpu, fb_ref, fb_gpu = _psnr_case(pkg, oracle, hip, sd, 8)
-    assert psnr >= 40.0, "PSNR %.2f dB" % psnr
+    assert psnr >= MIN_PSNR, "PSNR %.2f dB" % psnr
     assert abs(st_gpu.ref_scene_rays - st_ref.scene_rays) <= 0.002 * st_ref.scene_rays
+
+
+def test_render_chess_with_32_light_samples(pkg, oracle, hip, tree_env):
+    """BASELINE config 4 as the README labels it: `direct light sample = 32` (Scene::setDirectLightSample, Scene.hpp:114;
+    the shipped main never calls it and runs 4).  240x135 against the oracle here; the 1080p properties are below."""
+    sd = pkg.scenes.chess_scene(width=240, height=135, spp=4)
+    psnr, st_ref, st_gpu, fb_ref, fb_gpu = _psnr_case(pkg, oracle, hip, sd, 4, n_dir=32)
+    assert psnr >= MIN_PSNR, "PSNR %.2f dB" % psnr
+    assert st_gpu.ref_scene_rays / st_gpu.samples == pytest.approx(st_ref.scene_rays / st_ref.samples, rel=0.002)
+    assert st_ref.scene_rays / st_ref.samples > 40  # 32 shadow rays per vertex instead of 4 (SURVEY H7: 43.98)
+    tree_env("reference", "0")
+    fb_exact, _ = hip.HipScene(sd).render(spp=4, seed=1, n_dir_sample=32)
+    assert _same_bits(fb_ref, fb_exact).all()
 
 
 def _with_env(sd, seed=0):
@@ -146,7 +196,7 @@ def test_render_psnr_with_environment_map(pkg, oracle, hip):
     """Scene::sampleEnv (Scene.hpp:60-99): lat-long lookup with bilinear filtering, on misses and as the l_ind factor."""
     sd = _with_env(pkg.scenes.chess_scene(width=200, height=112, spp=8))
     psnr, st_ref, st_gpu, fb_ref, fb_gpu = _psnr_case(pkg, oracle, hip, sd, 8)
-    assert psnr >= 40.0, "PSNR %.2f dB" % psnr
+    assert psnr >= MIN_PSNR, "PSNR %.2f dB" % psnr
     sky = fb_ref[:20].reshape(-1, 3)
     assert sky.std(axis=0).max() > 0.01  # the map is actually visible in the sky rows
     # cast_rays with the map: per-path agreement
@@ -158,7 +208,7 @@ def test_render_psnr_with_environment_map(pkg, oracle, hip):
     ch = rng.integers(0, 3, size=n).astype(np.int32)
     o, d = os_.camera_rays(pix, smp, seed=3)
     ref, gpu = os_.cast_rays(o, d, pix, smp, ch, seed=3), hs.cast_rays(o, d, pix, smp, ch, seed=3)
-    assert (np.abs(ref - gpu) <= 1e-4 * np.maximum(1.0, np.abs(ref))).mean() >= 0.99
+    assert (~_same_bits(ref, gpu)).sum() <= 3  # atan2/acos of the lookup included
 
 
 def test_render_without_shadows_and_with_more_light_samples(pkg, oracle, hip):
@@ -166,12 +216,12 @@ def test_render_without_shadows_and_with_more_light_samples(pkg, oracle, hip):
     sd = pkg.scenes.cornell_rc(64, 64, 8)
     sd.enable_shadow = False
     psnr, *_ = _psnr_case(pkg, oracle, hip, sd, 8)
-    assert psnr >= 40.0, "no-shadow PSNR %.2f dB" % psnr
+    assert psnr >= MIN_PSNR, "no-shadow PSNR %.2f dB" % psnr
     sd = pkg.scenes.cornell_demo(64, 64, 4)
     os_, hs = oracle.OracleScene(sd), hip.HipScene(sd)
     fb_ref, _ = os_.render(spp=4, seed=1, n_dir_sample=9)
     fb_gpu, st = hs.render(spp=4, seed=1, n_dir_sample=9)
-    assert pkg.pngio.psnr_u8(pkg.pngio.tonemap_u8(fb_ref), pkg.pngio.tonemap_u8(fb_gpu)) >= 40.0
+    assert pkg.pngio.psnr_u8(pkg.pngio.tonemap_u8(fb_ref), pkg.pngio.tonemap_u8(fb_gpu)) >= MIN_PSNR
     assert st.direct_vertices <= st.shaded and st.shadow_rays <= 9 * st.direct_vertices
 
 
@@ -199,12 +249,13 @@ def test_two_pools_match_one_pool(pkg, hip, monkeypatch):
     assert st2.vertices == st1.vertices and st2.shaded == st1.shaded and st2.shadow_rays == st1.shadow_rays
 
 
-def test_host_schedule_variants_are_bit_identical(pkg, hip, monkeypatch):
+def test_host_schedule_variants_are_bit_identical(pkg, hip, hip_check, monkeypatch):
     """The frame does not depend on how the host drives the loop: kernels queued ahead of the counter read-back
     (default) or after it, a slow host (test hook), one stream instead of three, a tight pool that forces many
     regeneration rounds."""
     sd = pkg.scenes.cornell_demo(96, 96, 8)
     ref, st0 = hip.HipScene(sd).render(spp=8, seed=9, spp_per_pass=4)
+    # (MCPT_HOST_DELAY_US and MCPT_RING_START are test hooks: they exist only in the checking build)
     for env, kw in [({"MCPT_QUEUE_AHEAD": "0"}, {}), ({"MCPT_HOST_DELAY_US": "200"}, {}),
                     ({"MCPT_QUEUE_AHEAD": "1"}, {"pool_paths": 3 * 4096}), ({"MCPT_QUEUE_AHEAD": "0"}, {"pool_paths": 3 * 4096}),
                     ({"MCPT_OVERLAP": "0"}, {"pool_paths": 3 * 4096}),
@@ -212,11 +263,14 @@ def test_host_schedule_variants_are_bit_identical(pkg, hip, monkeypatch):
                     ({"MCPT_RING_START": "0xffffc000"}, {"pool_paths": 3 * 4096}), ({"MCPT_RING_START": "0xfffffff0"}, {})]:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        fb, st = hip.HipScene(sd).render(spp=8, seed=9, spp_per_pass=4, **kw)
+        hook = any(k in ("MCPT_HOST_DELAY_US", "MCPT_RING_START") for k in env)
+        fb, st = hip.HipScene(sd, library=hip_check if hook else None).render(spp=8, seed=9, spp_per_pass=4, **kw)
         for k in env:
             monkeypatch.delenv(k)
         assert np.array_equal(ref, fb, equal_nan=True), (env, kw)
-        assert (st.vertices, st.shaded, st.shadow_rays, st.closest_rays) == (st0.vertices, st0.shaded, st0.shadow_rays, st0.closest_rays)
+        assert (st.vertices, st.shaded, st.closest_rays) == (st0.vertices, st0.shaded, st0.closest_rays)
+        if not hook:  # (the checking build also evaluates the light samples the product skips)
+            assert st.shadow_rays == st0.shadow_rays
 
 
 def test_progressive_accumulation_matches_single_call(pkg, hip):

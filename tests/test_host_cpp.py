@@ -83,13 +83,33 @@ def test_conf_quirks_in_cpp_host(pkg, host_bins, tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_executable_renders_the_same_png(pkg, hip, host_bins, tmp_path):
-    """RayTracingDemo (C++ host over the C ABI) and the Python binding produce the same 8-bit image."""
-    out = str(tmp_path / "demo.png")
-    p = subprocess.run([host_bins[1], "--models", MODELS, "--width", "64", "--height", "64", "--spp", "8", "--output", out],
-                       cwd=str(tmp_path), capture_output=True, text=True)
-    assert p.returncode == 0 and "Rendering finished in" in p.stdout, p.stderr
-    img = pkg.pngio.read_png(out)
-    fb, _ = hip.HipScene(pkg.scenes.cornell_demo(64, 64, 8)).render(spp=8, seed=1)
-    assert np.array_equal(img[:, :, :3], pkg.pngio.tonemap_u8(fb))
-    assert (img[:, :, 3] == 255).all()
+@pytest.mark.parametrize("which", ["RayTracingDemo", "RayTracing"])
+def test_cpp_executables_render_the_oracle_image(pkg, hip, oracle, host_bins, tmp_path, which):
+    """host/RayTracingDemo and host/RayTracing (the reference's executable rebuilt over the C ABI: conf.json, OBJ files,
+    Renderer::Render, tone map, PNG) against the CPU oracle.  With the reference's tree topology the PNG is byte-identical to the
+    oracle's frame after the tone map of Renderer.cpp:95-103; with the default tree it is within 60 dB, and identical to what the
+    Python binding renders."""
+    if which == "RayTracingDemo":
+        exe, args, sd, spp = host_bins[1], ["--width", "64", "--height", "64", "--spp", "8"], pkg.scenes.cornell_demo(64, 64, 8), 8
+    else:
+        conf = json.loads(json.dumps(pkg.scenes.DEFAULT_CONF))
+        conf["camera"]["width"], conf["camera"]["height"], conf["renderer"]["spp"] = 160, 90, 6
+        conf["renderer"]["output"] = "ignored_by_override.png"
+        (tmp_path / "conf.json").write_text(json.dumps(conf))
+        exe, args, sd, spp = host_bins[0], [], pkg.scenes.chess_scene(conf), 6
+    fb_ref, _ = oracle.OracleScene(sd).render(spp=spp, seed=1)
+    want = pkg.pngio.tonemap_u8(fb_ref)
+    for tree_env, exact in (({"MCPT_BVH": "reference", "MCPT_QUANT_NODES": "0"}, True), ({}, False)):
+        out = str(tmp_path / ("out_%d.png" % exact))
+        env = {k: v for k, v in os.environ.items() if k not in ("MCPT_BVH", "MCPT_QUANT_NODES")}
+        env.update(tree_env)
+        p = subprocess.run([exe, "--models", MODELS, "--output", out] + args, cwd=str(tmp_path), capture_output=True, text=True, env=env)
+        assert p.returncode == 0 and "Rendering finished in" in p.stdout, p.stderr
+        img = pkg.pngio.read_png(out)
+        assert (img[:, :, 3] == 255).all()
+        if exact:
+            assert np.array_equal(img[:, :, :3], want), "%d bytes differ" % int((img[:, :, :3] != want).sum())
+        else:
+            assert pkg.pngio.psnr_u8(want, img[:, :, :3]) >= 60.0
+            fb, _ = hip.HipScene(sd).render(spp=spp, seed=1)
+            assert np.array_equal(img[:, :, :3], pkg.pngio.tonemap_u8(fb))
