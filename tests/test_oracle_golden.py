@@ -3,7 +3,10 @@
 The reference has no tests and no golden vectors, and it cannot be built here (Eigen3 is missing), so the
 pins are, in decreasing strength:
   1. cornellbox_demo.png -- the one output image the reference ships for its DEMO scene (tests/golden/
-     reference_cornellbox_demo.png, 384x384).  The oracle must reproduce it statistically.
+     reference_cornellbox_demo.png, 384x384).  The oracle must reproduce it statistically: block-wise over the frame, and
+     per object / material region (every BSDF type of Material.hpp has its own object in that scene) within 3-5 %.
+     The chess scene has no such artefact: the reference's two 1920x1080 PNGs were rendered with an environment map that is
+     missing from the snapshot / with a back wall that main.cpp:312 no longer adds -- chess radiometry is "parity unpinned".
   2. the reference's exact call counts per sample measured from its compiled sources during the survey
      (SURVEY.md Appendix D): rays, castRay invocations, BVH node visits and triangle tests per sample.
   3. closed-form values of the material functions at configurations where the reference's formulas
@@ -36,22 +39,99 @@ def _blocks(a, b):
     return a.reshape(h // b, b, w // b, b, c).mean(axis=(1, 3))
 
 
-def test_oracle_reproduces_reference_demo_image(pkg, oracle):
-    """Oracle render of the DEMO scene (main.cpp:99-129) vs the reference's own cornellbox_demo.png."""
+@pytest.fixture(scope="module")
+def demo_render(pkg, oracle):
+    """Two independent oracle renders (seeds 1, 2; 64 spp each) of the DEMO scene at 192 x 192: each pixel integrates a 2 x 2
+    block of the reference's 384 x 384 frame."""
+    sd = pkg.scenes.cornell_demo(192, 192, 64)
+    osc = oracle.OracleScene(sd)
+    return [osc.render(spp=64, seed=s)[0].astype(np.float64) for s in (1, 2)]
+
+
+def test_oracle_reproduces_reference_demo_image(pkg, oracle, demo_render):
+    """Oracle render of the DEMO scene (main.cpp:99-129) vs the reference's own cornellbox_demo.png, block-wise."""
     ref = pkg.pngio.read_png(os.path.join(GOLDEN, "reference_cornellbox_demo.png"))[:, :, :3]
     assert ref.shape == (384, 384, 3)
-    sd = pkg.scenes.cornell_demo(192, 192, 40)  # each pixel integrates a 2x2 block of the 384x384 frame
-    fb, st = oracle.OracleScene(sd).render(spp=40, seed=1)
-    ours = pkg.pngio.tonemap_u8(fb)
+    fb = 0.5 * (demo_render[0] + demo_render[1])
+    ours = pkg.pngio.tonemap_u8(fb.astype(np.float32))
     # compare 16x16 blocks of the reference with 8x8 blocks of ours, in linear radiance
     A = _blocks(_lin(ref), 16)
     B = _blocks(_lin(ours), 8)
     rel_mean = np.abs(A.mean(axis=(0, 1)) - B.mean(axis=(0, 1))) / A.mean(axis=(0, 1))
-    assert (rel_mean < 0.03).all(), "per-channel mean radiance differs: %s" % rel_mean
+    assert (rel_mean < 0.02).all(), "per-channel mean radiance differs: %s" % rel_mean
     rel_l1 = np.abs(A - B).mean() / A.mean()
-    assert rel_l1 < 0.05, "block-wise relative L1 %.4f" % rel_l1
+    assert rel_l1 < 0.04, "block-wise relative L1 %.4f" % rel_l1
     corr = np.corrcoef(A.ravel(), B.ravel())[0, 1]
-    assert corr > 0.99, "block correlation %.4f" % corr
+    assert corr > 0.995, "block correlation %.4f" % corr
+
+
+def demo_region_masks(pkg, oracle, W=384, H=384):
+    """Which object each pixel CENTRE of the DEMO frame sees (orc_intersect on un-jittered camera rays, Renderer.cpp:44-55),
+    eroded by two pixels so that a pixel's jitter footprint stays on one object.  floor.obj holds floor, ceiling and back wall
+    (two triangles each), which are separated by triangle index."""
+    sd = pkg.scenes.cornell_demo(W, H, 1)
+    cam = sd.camera
+    f32 = np.float32
+    scale, aspect = f32(np.tan(np.deg2rad(float(cam["fov"]) * 0.5))), f32(W / H)
+    i, j = np.meshgrid(np.arange(W), np.arange(H))
+    d = np.stack([(1 - 2 * (i + 0.5) / W) * aspect * scale, (1 - 2 * (j + 0.5) / H) * scale, np.ones((H, W))], -1).reshape(-1, 3)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(f32)
+    dw = (d @ np.asarray(cam["orientation"]).reshape(3, 3).T).astype(f32)
+    o = np.tile(np.asarray(cam["position"], f32), (W * H, 1))
+    _, prim = oracle.OracleScene(sd).intersect(o, dw)
+    prim = prim.reshape(H, W)
+    nt = len(sd.triangles)
+    region = np.full((H, W), -1)
+    for k, ob in enumerate(sd.objects):  # Scene::Add order, main.cpp:117-125
+        if ob["kind"] == 0:
+            m = (prim >= ob["first_tri"]) & (prim < ob["first_tri"] + ob["n_tri"])
+            region[m] = 10 * k + (prim[m] // 2 if k == 0 else 0)
+        else:
+            region[prim == nt + k] = 10 * k
+    from numpy.lib.stride_tricks import sliding_window_view
+    win = sliding_window_view(np.pad(region, 2, mode="edge"), (5, 5))
+    inner = (win == region[:, :, None, None]).all(axis=(2, 3))
+    names = {0: "floor (rough white conductor)", 1: "ceiling", 2: "back wall", 10: "short box (green_mirror)",
+             20: "tall box (rough_plastic)", 30: "left wall (rough_red_conductor)", 40: "right wall (gold_conductor)", 50: "light",
+             60: "glass sphere (smooth_glass)", 70: "plastic sphere (clear_rough_plastic)", 80: "mirror sphere (silver_mirror)"}
+    return {name: (region == r) & inner for r, name in names.items()}
+
+
+def test_oracle_matches_reference_demo_image_per_material_region(pkg, oracle, demo_render, capsys):
+    """The tight pin: mean linear radiance of every object of the DEMO scene -- one region per material preset of
+    main.cpp:34-97 that the scene uses, including the three spheres (Material.hpp:330-408: smooth dielectric, rough
+    dielectric, smooth conductor) -- against cornellbox_demo.png, the image the reference's authors rendered with their own
+    build (spp 2048).  A wrong factor in any one BSDF branch moves that object's mean by far more than the bound.
+
+    PNG bytes are truncated 8-bit values of 255 c^0.45 (Renderer.cpp:95-103): they are linearised as ((v + 0.5)/255)^(1/0.45);
+    saturated pixels are left out (the light is checked on its own).  Ours: two seeds x 64 spp at 192 x 192, averaged.
+    Bound: 3 % relative for regions of >= 5000 pixels, 5 % for the smaller ones (the two seeds differ from each other by up to
+    1.5 % / 4 % respectively at this sample count: the Monte Carlo part of the bound)."""
+    ref = pkg.pngio.read_png(os.path.join(GOLDEN, "reference_cornellbox_demo.png"))[:, :, :3]
+    lin = ((ref.astype(np.float64) + 0.5) / 255.0) ** (1 / 0.45)
+    sat = (ref == 255).any(axis=2)
+    up = [np.repeat(np.repeat(fb, 2, 0), 2, 1) for fb in demo_render]
+    masks = demo_region_masks(pkg, oracle)
+    rows = []
+    for name, m in masks.items():
+        if name == "light":
+            # Scene.cpp:102-107: clamp(0, 1, emission |wo.n|) = 1 in every channel => byte 255, in the PNG and in ours
+            assert m.sum() > 500 and (ref[m] == 255).mean() > 0.999
+            assert (pkg.pngio.tonemap_u8(up[0][m].astype(np.float32)) == 255).mean() > 0.999
+            continue
+        m = m & ~sat
+        assert m.sum() >= 1000, (name, int(m.sum()))
+        a = lin[m].mean(axis=0)
+        b1, b2 = up[0][m].mean(axis=0), up[1][m].mean(axis=0)
+        rel = (0.5 * (b1 + b2) - a) / a
+        rows.append((name, int(m.sum()), rel, (b1 - b2) / a))
+        bound = 0.03 if m.sum() >= 5000 else 0.05
+        assert np.abs(rel).max() < bound, "%s: mean radiance differs from the reference image by %s (bound %.2f)" % (name, np.round(rel, 4), bound)
+    with capsys.disabled():
+        print()
+        for name, n, rel, seed in rows:
+            print("[pin] %-38s %6d px  (ours - png)/png = %s   seed1 - seed2 = %s" % (name, n, np.round(rel, 4), np.round(seed, 4)))
+    assert len(rows) == 10
 
 
 def test_oracle_call_counts_match_reference_cornell(pkg, oracle):
