@@ -182,21 +182,45 @@ MCPT_DI bool ray_is_plain(const Ray &r) {  // all three reciprocals finite (no z
 }
 
 // Triangle::getIntersection, Triangle.hpp:222-252 (two-sided Moller-Trumbore, double det chain).
+//
+// The reference divides first (`det_inv = 1. / det`, a double division) and rejects afterwards; about two thirds of the
+// candidates are rejected on u or v.  Every rejection that can be decided WITHOUT the quotient is decided first, with the
+// reference's outcome exactly:
+//   * det, u's numerator a = tvec.pvec, v's numerator b = dir.qvec and t's numerator c = e2.qvec are float dot products;
+//     the reference's doubles are their exact widenings.  det_inv = RN(1/det) has the sign of det and, like the products
+//     a * det_inv etc., cannot underflow (|det| >= 1e-4, |numerator| >= 2^-149), so  u < 0  <=>  a and det have opposite
+//     signs (a == 0 gives u = +-0, not < 0); the same holds for v < 0 and t < 0.  |det| < EPSILON is the same comparison
+//     in float as in double.
+//   * u > 1 and u + v > 1 are certain when the numerators exceed |det| by a factor 1.00001 (float rounding of the
+//     comparison's operands is 6e-8 relative, the double chain's 3e-16); anything closer goes through the exact chain.
+// Only candidates that survive these tests pay for the division.
 MCPT_DI bool tri_hit(const TriGeom &g, const Ray &r, double &t_out, double &u_out, double &v_out) {
     const f3 v0 = mk3(g.v0[0], g.v0[1], g.v0[2]);
     const f3 e1 = mk3(g.e1x, g.e1yz[0], g.e1yz[1]);
     const f3 e2 = mk3(g.e2xy[0], g.e2xy[1], g.e2z);
     const f3 pvec = cross(r.d, e2);
-    const double det = (double)dot(e1, pvec);
-    if (fabs(det) < (double)kEps) return false;
-    const double det_inv = 1. / det;
+    const float det_f = dot(e1, pvec);
+    if (fabsf(det_f) < kEps) return false;  // also false for a NaN det, as fabs(det) < EPSILON is
     const f3 tvec = r.o - v0;
-    const double u = (double)dot(tvec, pvec) * det_inv;
-    if (u < 0 || u > 1) return false;
+    const float a_f = dot(tvec, pvec);
+    const float ad = fabsf(det_f), lim = ad * 1.00001f;
+    const float a_s = (det_f < 0.f) ? -a_f : a_f;  // numerator of u with the sign of det folded in: u = a_s / |det|
+    if (a_s < 0.f || a_s > lim) return false;    // u < 0, or u > 1 for certain
     const f3 qvec = cross(tvec, e1);
-    const double v = (double)dot(r.d, qvec) * det_inv;
+    const float b_f = dot(r.d, qvec);
+    const float b_s = (det_f < 0.f) ? -b_f : b_f;
+    if (b_s < 0.f || a_s + b_s > lim) return false;  // v < 0, or u + v > 1 for certain
+    const float c_f = dot(e2, qvec);
+    const float c_s = (det_f < 0.f) ? -c_f : c_f;
+    if (c_s < 0.f) return false;                   // t < 0
+    // the reference's chain for the survivors (NaN numerators arrive here too and fail the comparisons below as they do there)
+    const double det = (double)det_f;
+    const double det_inv = 1. / det;
+    const double u = (double)a_f * det_inv;
+    if (u < 0 || u > 1) return false;
+    const double v = (double)b_f * det_inv;
     if (v < 0 || u + v > 1) return false;
-    const double t = (double)dot(e2, qvec) * det_inv;
+    const double t = (double)c_f * det_inv;
     if (t < 0) return false;
     t_out = t;
     u_out = u;

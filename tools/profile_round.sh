@@ -12,8 +12,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/benc
 f=$(find $O/kt -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_overlap.csv
 t=$(find $O/kt -name "*kernel_trace.csv" | head -1); python3 $R/tools/trace_busy.py $t 0.3 > $O/trace_busy_overlap.txt
 rm -rf $O/kt; echo "kernel trace done"
-export MCPT_OVERLAP=0
-SMALL="--steps 1 --warmup 0 --spp-per-step 64 --no-cpu-baseline --no-psnr"
+SMALL="--serialized --steps 1 --warmup 0 --spp-per-step 64 --no-cpu-baseline --no-psnr"
+python3 $R/bench.py $SMALL > $O/bench_serialized_64spp.json 2>> $O/bench.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt0 -- python3 $R/bench.py $SMALL > $O/kt0.log 2>&1 || exit 1
 f=$(find $O/kt0 -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_no_overlap_64spp.csv; rm -rf $O/kt0
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do
