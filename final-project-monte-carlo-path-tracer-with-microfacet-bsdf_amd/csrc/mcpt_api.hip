@@ -621,6 +621,7 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
         return fail(MCPT_ERR_ARG, "mcpt_render: width/height/spp/n_dir_sample/rr_rate must be positive");
     if ((uint64_t)cam->width * cam->height > 0x7fffffffull) return fail(MCPT_ERR_ARG, "mcpt_render: frame too large");
     HIP_TRY(hipSetDevice(sc->device));
+    (void)hipGetLastError();  // an earlier, already reported failure of this thread must not be taken for one of this call
     const auto t0 = std::chrono::steady_clock::now();
     const int W = cam->width, H = cam->height;
 

@@ -118,6 +118,9 @@ void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_i
 // Shades list `cur_idx` (at most n_cur_max records; the true count is read from the device counter) into the other list.
 void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, Scratch X, int cur_idx, uint32_t n_cur_max,
                   hipStream_t s);
+// Multi-GPU merge helpers (csrc/mcpt_multi.hip): zero the pixels rank `rank` does not own (tile rule of mcpt_params); a += b.
+void launch_mask_unowned(float *fb, int width, int height, int tile, int rank, int nranks, hipStream_t s);
+void launch_add_frame(float *a, const float *b, uint32_t n, hipStream_t s);
 void launch_debug_fmath(int kind, uint32_t n, const float *x, const float *y, float *out, hipStream_t s);
 void launch_accumulate(const float *result, const uint32_t *pixel_list, uint32_t n_pix, int32_t s_pass, float spp_total,
                        float *fb, hipStream_t s);

@@ -950,6 +950,22 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float *__restrict__
     fb[(size_t)m * 3 + c] = acc;
 }
 
+__global__ __launch_bounds__(kBlock) void k_mask_unowned(float *fb, int W, int H, int tile, int rank, int nranks) {
+    const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
+    if (m >= (uint32_t)W * (uint32_t)H) return;
+    const int i = (int)(m % (uint32_t)W), j = (int)(m / (uint32_t)W);
+    const int tx = (W + tile - 1) / tile;
+    if (((j / tile) * tx + i / tile) % nranks == rank) return;  // owned (mcpt_params: tile_size / rank / nranks)
+    fb[(size_t)m * 3] = 0.f;
+    fb[(size_t)m * 3 + 1] = 0.f;
+    fb[(size_t)m * 3 + 2] = 0.f;
+}
+
+__global__ __launch_bounds__(kBlock) void k_add_frame(float *__restrict__ a, const float *__restrict__ b, uint32_t n) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) a[i] += b[i];
+}
+
 __global__ __launch_bounds__(kBlock) void k_debug_fmath(int kind, uint32_t n, const float *x, const float *y, float *out) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -1071,6 +1087,15 @@ void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, 
                   hipStream_t s) {
     if (n_cur_max == 0) return;
     hipLaunchKernelGGL(k_shade, dim3((n_cur_max + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, s, S, C, cur, next, X, cur_idx);
+}
+
+void launch_mask_unowned(float *fb, int width, int height, int tile, int rank, int nranks, hipStream_t s) {
+    hipLaunchKernelGGL(k_mask_unowned, dim3(blocks((uint32_t)width * (uint32_t)height)), dim3(kBlock), 0, s, fb, width, height, tile, rank, nranks);
+}
+
+void launch_add_frame(float *a, const float *b, uint32_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_add_frame, dim3(blocks(n)), dim3(kBlock), 0, s, a, b, n);
 }
 
 void launch_debug_fmath(int kind, uint32_t n, const float *x, const float *y, float *out, hipStream_t s) {

@@ -17,6 +17,7 @@ CHECK_LIB_PATH = os.path.join(HERE, "libmcpt_hip_check.so")  # the checking buil
 
 EXPORTS = ["mcpt_scene_create", "mcpt_scene_destroy", "mcpt_render", "mcpt_render_device", "mcpt_intersect",
            "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_bvh_dump", "mcpt_debug_fmath", "mcpt_debug_counters",
+           "mcpt_group_create", "mcpt_group_render", "mcpt_group_size", "mcpt_group_destroy", "mcpt_group_last_error",
            "mcpt_last_error", "mcpt_version"]
 
 
@@ -89,6 +90,15 @@ def lib(path=None):
         L.mcpt_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64] + [C.c_void_p] * 4
         L.mcpt_debug_fmath.restype = C.c_int
         L.mcpt_debug_fmath.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcpt_group_create.restype = C.c_int
+        L.mcpt_group_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mcpt_group_render.restype = C.c_int
+        L.mcpt_group_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]
+        L.mcpt_group_size.restype = C.c_int
+        L.mcpt_group_size.argtypes = [C.c_void_p]
+        L.mcpt_group_destroy.restype = None
+        L.mcpt_group_destroy.argtypes = [C.c_void_p]
+        L.mcpt_group_last_error.restype = C.c_char_p
         L.mcpt_debug_counters.restype = C.c_int
         L.mcpt_debug_counters.argtypes = [C.c_void_p, C.c_void_p]
         _libs[path] = L
@@ -235,6 +245,46 @@ class HipScene:
         d = np.zeros((n, 3), dtype=np.float32)
         _check(self.L.mcpt_camera_rays(self.h, _ptr(cam), int(seed), n, _ptr(px), _ptr(sm), _ptr(o), _ptr(d)), L=self.L)
         return o, d
+
+
+class HipGroup:
+    """One replica of the scene per listed device; render() = mcpt_group_render (tile partition + RCCL merge inside the library)."""
+
+    def __init__(self, sd, devices):
+        self.sd = sd
+        self._keep = []
+        self.L = lib()
+        d = _make_desc(sd, self._keep)
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        self.h = None
+        rc = self.L.mcpt_group_create(C.byref(d), len(dev), _ptr(dev), C.byref(h))
+        if rc != 0:
+            raise McptError(rc, self.L.mcpt_group_last_error().decode("utf-8", "replace"))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mcpt_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, camera=None, fb=None, **kw):
+        cam = np.ascontiguousarray(camera if camera is not None else self.sd.camera)
+        W, H = int(cam["width"].reshape(-1)[0]), int(cam["height"].reshape(-1)[0])
+        if fb is None:
+            fb = np.zeros((H, W, 3), dtype=np.float32)
+        p = HipScene.params(self, **kw)
+        st = Stats()
+        rc = self.L.mcpt_group_render(self.h, _ptr(cam), C.byref(p), _ptr(fb), C.byref(st))
+        if rc != 0:
+            raise McptError(rc, self.L.mcpt_group_last_error().decode("utf-8", "replace"))
+        return fb, st
 
 
 _FMATH_SCENE = None

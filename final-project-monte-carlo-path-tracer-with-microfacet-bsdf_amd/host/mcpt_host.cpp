@@ -83,7 +83,10 @@ MeshTriangle::MeshTriangle(const std::string &filename, Material *mt, const Vect
 }
 
 // ------------------------------------------------------------------------------------------------ Scene
-Scene::~Scene() { mcpt_scene_destroy(gpu); }
+Scene::~Scene() {
+    mcpt_scene_destroy(gpu);
+    mcpt_group_destroy(group);
+}
 
 void Scene::loadEnvMap(const std::string &path) {
     std::vector<uint8_t> rgba;
@@ -168,7 +171,11 @@ void Scene::buildBVH() {
     }
     mcpt_scene_destroy(gpu);
     gpu = nullptr;
-    if (mcpt_scene_create(&d, -1, &gpu) != MCPT_OK) std::cerr << "mcpt: " << mcpt_last_error() << std::endl;
+    mcpt_group_destroy(group);
+    group = nullptr;
+    if (mcpt_scene_create(&d, devices.empty() ? -1 : devices[0], &gpu) != MCPT_OK) std::cerr << "mcpt: " << mcpt_last_error() << std::endl;
+    if (gpu && devices.size() > 1 && mcpt_group_create(&d, (int)devices.size(), devices.data(), &group) != MCPT_OK)
+        std::cerr << "mcpt: " << mcpt_group_last_error() << std::endl;
 }
 
 mcpt_params Scene::params(int spp) const {
@@ -235,12 +242,14 @@ void Renderer::Render(const Scene &scene) {
     const mcpt_camera c = scene.cameraDesc();
     const mcpt_params p = scene.params(spp);
     mcpt_stats st{};
-    const int rc = mcpt_render(scene.handle(), &c, &p, framebuffer.data(), &st);  // Renderer.cpp:36-90
-    if (rc != MCPT_OK) std::cerr << "mcpt: " << mcpt_last_error() << std::endl;
+    // Renderer.cpp:36-90
+    const int rc = scene.groupHandle() ? mcpt_group_render(scene.groupHandle(), &c, &p, framebuffer.data(), &st)
+                                       : mcpt_render(scene.handle(), &c, &p, framebuffer.data(), &st);
+    if (rc != MCPT_OK) std::cerr << "mcpt: " << (scene.groupHandle() ? mcpt_group_last_error() : mcpt_last_error()) << std::endl;
     if (rc != MCPT_OK && rc != MCPT_ERR_OVERFLOW) return;
     std::cout << "[mcpt] " << st.samples / 1e6 << " Msamples in " << st.ms_total << " ms = "
               << (st.ms_total > 0 ? st.samples / st.ms_total / 1e3 : 0.0) << " Msamples/s, " << st.iterations
-              << " wavefront iterations" << std::endl;
+              << " wavefront iterations" << (scene.groupHandle() ? " on " + std::to_string(mcpt_group_size(scene.groupHandle())) + " GPU replicas" : std::string()) << std::endl;
 
     std::cout << "Writing image to " << path << std::endl;
     std::vector<unsigned char> raw((size_t)4 * camera.width * camera.height);

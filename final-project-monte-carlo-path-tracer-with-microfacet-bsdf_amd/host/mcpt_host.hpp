@@ -222,6 +222,10 @@ class Scene {
 
     // used by Renderer
     mcpt_scene *handle() const { return gpu; }
+    // More than one entry: the frame is rendered by all listed GPUs (mcpt_group_*: tile partition + RCCL merge inside the
+    // library; main() stays single-threaded).  Call before buildBVH.  {0, 0} rehearses the schedule on one GPU.
+    void setDevices(const std::vector<int> &d) { devices = d; }
+    mcpt_group *groupHandle() const { return group; }
     mcpt_params params(int spp) const;
     mcpt_camera cameraDesc() const;
     // flat description (also used by the tests to compare with the Python assembly)
@@ -232,6 +236,8 @@ class Scene {
 
   private:
     mcpt_scene *gpu = nullptr;
+    mcpt_group *group = nullptr;
+    std::vector<int> devices;
 };
 
 // ============================================================================ renderer

@@ -4,6 +4,7 @@
 // renderer.path and renderer.parrallelism are ignored; addDiamond only has to be present; lightBrightness must be a
 // JSON float.  Additions: optional command-line overrides, because DEMO hard-codes 384x384 / spp 2048:
 //   --width N --height N --spp N --output FILE --conf FILE --models DIR
+//   --gpus N      render on GPUs 0..N-1 (tile partition + RCCL merge inside the library); --devices 0,0 lists them explicitly
 //   --dump FILE   write the flattened scene (what mcpt_scene_create receives) and exit without touching the GPU
 #include <chrono>
 #include <cstring>
@@ -44,6 +45,17 @@ int main(int argc, char **argv) {
         else if (a == "--conf") conf_path = argv[i + 1];
         else if (a == "--models") models = argv[i + 1];
         else if (a == "--dump") dump_path = argv[i + 1];
+        else if (a == "--gpus") {
+            std::vector<int> dev;
+            for (int k = 0; k < std::atoi(argv[i + 1]); ++k) dev.push_back(k);
+            scene.setDevices(dev);
+        } else if (a == "--devices") {
+            std::vector<int> dev;
+            std::stringstream ss(argv[i + 1]);
+            std::string tok;
+            while (std::getline(ss, tok, ',')) dev.push_back(std::atoi(tok.c_str()));
+            scene.setDevices(dev);
+        }
     }
     bool use_diamond = false;
     const std::string model_quality = "low";  // the conf value is read after the paths are composed (main.cpp:24-26,200-202)

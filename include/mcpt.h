@@ -153,6 +153,20 @@ int mcpt_cast_rays(mcpt_scene *scene, const mcpt_params *params, int64_t n, cons
 int mcpt_camera_rays(mcpt_scene *scene, const mcpt_camera *camera, uint32_t seed, int64_t n, const uint32_t *pixel,
                      const uint32_t *sample, float *origins, float *dirs);
 
+/* ---- Multi-GPU inside the boundary.  The caller stays single-threaded like the reference's main() (Renderer::Render blocks,
+ * main.cpp:333): a group holds one replica of the scene per device; mcpt_group_render partitions the frame into interleaved
+ * tiles over the devices (tile_size of `params`, default 32; its rank/nranks fields are ignored), drives every device from its
+ * own host thread, sums the per-device frames into the first device's with one RCCL ncclReduce over xGMI and returns the
+ * merged frame in fb_host.  The result is bit-identical to mcpt_render on one GPU (disjoint pixels, same Philox keys).
+ * `devices`: distinct HIP device indices; as a rehearsal on a one-GPU box every entry may name the SAME device (the merge is
+ * then a kernel on that device; RCCL is neither loaded nor needed).  Errors of these three calls: mcpt_group_last_error(). */
+typedef struct mcpt_group mcpt_group;
+int mcpt_group_create(const mcpt_scene_desc *desc, int n_devices, const int *devices, mcpt_group **out);
+int mcpt_group_render(mcpt_group *group, const mcpt_camera *camera, const mcpt_params *params, float *fb_host, mcpt_stats *stats);
+int mcpt_group_size(const mcpt_group *group);
+void mcpt_group_destroy(mcpt_group *group);
+const char *mcpt_group_last_error(void);
+
 /* Scene statistics for reporting (BVH nodes, tree height, bytes resident in HBM). */
 typedef struct {
     int32_t n_nodes, bvh_height, n_lights, n_prims;

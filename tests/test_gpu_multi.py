@@ -1,0 +1,90 @@
+"""Multi-GPU on a one-GPU box.
+
+Inside the boundary: mcpt_group_* with every entry naming device 0 rehearses the schedule the library runs on N GPUs -- one
+replica and one host thread per entry, interleaved-tile partition, merge into the first frame -- and must reproduce the
+one-GPU frame bit for bit (with distinct devices the merge is one RCCL ncclReduce; that leg needs an N-GPU node).
+Outside: bench.py's one-process-per-GPU path (torch.distributed) is run with 2 ranks sharing the GPU over gloo, in fresh child
+processes exactly as the driver launches it, and must write the PNG the 1-rank run writes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "final-project-monte-carlo-path-tracer-with-microfacet-bsdf_amd", "host")
+MODELS = os.path.join(ROOT, "assets", "models")
+
+
+def test_group_rehearsal_is_bit_identical_to_one_gpu(pkg, hip):
+    sd = pkg.scenes.chess_scene(width=200, height=120, spp=6)
+    one, st1 = hip.HipScene(sd).render(spp=6, seed=4)
+    for n in (2, 3):
+        g = hip.HipGroup(sd, [0] * n)
+        fb, st = g.render(spp=6, seed=4)
+        assert np.array_equal(one, fb, equal_nan=True), n
+        assert (st.samples, st.vertices, st.shaded, st.closest_rays, st.shadow_rays) == (st1.samples, st1.vertices, st1.shaded, st1.closest_rays, st1.shadow_rays)
+        # progressive accumulation through the group: two calls of 3 spp == one call of 6 spp
+        fb2, _ = g.render(spp=3, spp_total=6, sample_offset=0, seed=4)
+        fb2, _ = g.render(fb=fb2, spp=3, spp_total=6, sample_offset=3, accumulate=1, seed=4)
+        assert np.array_equal(one, fb2, equal_nan=True), n
+        g.close()
+
+
+def test_group_argument_errors(pkg, hip):
+    sd = pkg.scenes.cornell_rc(32, 32, 1)
+    with pytest.raises(hip.McptError):
+        hip.HipGroup(sd, [0, 0, 1])  # neither all-equal nor all-distinct
+    with pytest.raises(hip.McptError):
+        hip.HipGroup(sd, [0, 99])  # no such device
+    g = hip.HipGroup(sd, [0])  # a group of one is just the scene
+    fb, _ = g.render(spp=2, seed=1)
+    ref, _ = hip.HipScene(sd).render(spp=2, seed=1)
+    assert np.array_equal(fb, ref)
+
+
+def test_cpp_executable_on_two_replicas(pkg, hip, tmp_path):
+    subprocess.check_call(["make", "-C", HOST], stdout=subprocess.DEVNULL)
+    exe = os.path.join(HOST, "RayTracingDemo")
+    outs = []
+    for extra, name in (([], "one.png"), (["--devices", "0,0"], "two.png")):
+        out = str(tmp_path / name)
+        p = subprocess.run([exe, "--models", MODELS, "--width", "96", "--height", "64", "--spp", "6", "--output", out] + extra,
+                           cwd=str(tmp_path), capture_output=True, text=True)
+        assert p.returncode == 0 and "Rendering finished in" in p.stdout, p.stderr
+        outs.append(open(out, "rb").read())
+    assert "2 GPU replicas" in p.stdout
+    assert outs[0] == outs[1]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_bench_two_ranks_write_the_one_rank_png(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), both ranks on cuda:0, reduce
+    through gloo; the PNG of the reduced frame is byte-identical to the 1-rank run's."""
+    common = ["--steps", "2", "--warmup", "1", "--spp-per-step", "3", "--width", "320", "--height", "180", "--no-cpu-baseline", "--no-psnr"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    one = str(tmp_path / "one.png")
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--save-png", one] + common,
+                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    two = str(tmp_path / "two.png")
+    p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo",
+                         "--save-png", two] + common, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert p2.returncode == 0, p2.stderr[-2000:]
+    j1 = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][-1])
+    j2 = json.loads([l for l in p2.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["value"] > 0
+    assert j2["job"]["vertices_per_sample"] == j1["job"]["vertices_per_sample"]  # the same work, split over two ranks
+    assert open(one, "rb").read() == open(two, "rb").read()
