@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "mcpt_kernels.h"
+#include "mcpt_lbvh.h"
 
 using namespace mcpt;
 
@@ -208,6 +209,7 @@ struct Timer {
 
 struct mcpt_scene {
     int device = 0;
+    int32_t n_inner = 0;  // inner nodes of the traversal tree (0: the root is a leaf)
     Knobs knobs;
     mcpt_scene_info info{};
     DevBuf<Node> nodes;
@@ -812,7 +814,9 @@ const char *mcpt_version(void) {
 #endif
 }
 
-int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out) {
+int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out) { return mcpt_scene_create_ex(desc, device, nullptr, out); }
+
+int mcpt_scene_create_ex(const mcpt_scene_desc *desc, int device, const mcpt_build_options *options, mcpt_scene **out) {
     if (!desc || !out) return fail(MCPT_ERR_ARG, "mcpt_scene_create: null argument");
     *out = nullptr;
     int ndev = 0;
@@ -826,8 +830,17 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
 
     HostScene hs;
     const char *err = "";
-    const int rc = build_host_scene(*desc, hs, &err);
+    const auto t_build = std::chrono::steady_clock::now();
+    BuildChoice choice = resolve_build_choice(options);
+    // (a single primitive has no inner node: nothing for the device builder to do)
+    if (choice.builder == MCPT_BUILD_GPU_LBVH && desc->objects) {
+        int64_t n_prim = desc->n_triangles;
+        for (int i = 0; i < desc->n_objects; ++i) n_prim += desc->objects[i].kind == MCPT_OBJ_SPHERE ? 1 : 0;
+        if (n_prim < 2) choice.builder = MCPT_BUILD_SAH;
+    }
+    const int rc = build_host_scene(*desc, hs, &err, choice);
     if (rc != MCPT_OK) return fail(rc, std::string("mcpt_scene_create: ") + err);
+    const auto t_upload = std::chrono::steady_clock::now();
 
     mcpt_scene *sc = new (std::nothrow) mcpt_scene();
     if (!sc) return fail(MCPT_ERR_OOM, "mcpt_scene_create: host allocation failed");
@@ -853,8 +866,10 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
     auto up = [&](auto &buf, const auto &vec) {
         if (e == hipSuccess) e = upload(buf, vec);
     };
-    up(sc->nodes, hs.nodes);
-    if (!hs.qnodes.empty()) up(sc->qnodes, hs.qnodes);
+    if (hs.builder != 2) {
+        up(sc->nodes, hs.nodes);
+        if (!hs.qnodes.empty()) up(sc->qnodes, hs.qnodes);
+    }
     up(sc->tri_geom, hs.tri_geom);
     up(sc->tri_shade, hs.tri_shade);
     up(sc->spheres, hs.spheres);
@@ -867,10 +882,46 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
         mcpt_scene_destroy(sc);
         return fail(e == hipErrorOutOfMemory ? MCPT_ERR_OOM : MCPT_ERR_HIP, std::string("scene upload: ") + hipGetErrorString(e));
     }
+    double gpu_build_ms = 0.0;
+    if (hs.builder == 2) {  // the traversal tree is built on the device from the caller's triangles (csrc/mcpt_lbvh.hip)
+        const auto tb = std::chrono::steady_clock::now();
+        const int n_sph = (int)hs.sphere_objects.size();
+        const int n_prim = hs.n_triangles + n_sph;
+        DevBuf<mcpt_triangle> d_tris;
+        DevBuf<int32_t> d_sph;
+        e = d_tris.alloc((size_t)hs.n_triangles);
+        if (e == hipSuccess && hs.n_triangles > 0) e = hipMemcpy(d_tris.p, desc->triangles, (size_t)hs.n_triangles * sizeof(mcpt_triangle), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = upload(d_sph, hs.sphere_objects);
+        if (e == hipSuccess) e = sc->nodes.alloc((size_t)n_prim - 1);
+        if (e == hipSuccess) e = sc->qnodes.alloc((size_t)n_prim - 1);
+        LbvhResult R;
+        if (e == hipSuccess) e = build_lbvh_device(d_tris.p, hs.n_triangles, d_sph.p, sc->spheres.p, n_sph, choice.quantise, sc->nodes.p, sc->qnodes.p, &R, nullptr);
+        if (e != hipSuccess) {
+            mcpt_scene_destroy(sc);
+            return fail(e == hipErrorOutOfMemory ? MCPT_ERR_OOM : MCPT_ERR_HIP, std::string("GPU BVH build: ") + hipGetErrorString(e));
+        }
+        if (R.height > kMaxBvhHeight) {
+            mcpt_scene_destroy(sc);
+            return fail(MCPT_ERR_LIMIT, "the GPU-built BVH is deeper than the traversal stack (kMaxBvhHeight); use MCPT_BUILD_SAH");
+        }
+        hs.root = R.root;
+        hs.height = R.height;
+        for (int k = 0; k < 3; ++k) {
+            hs.root_min[k] = R.root_min[k];
+            hs.root_max[k] = R.root_max[k];
+            hs.q_origin[k] = R.q_origin[k];
+            hs.q_cell[k] = R.q_cell[k];
+        }
+        if (!R.quantised) sc->qnodes.release();
+        sc->n_inner = R.n_nodes;
+        gpu_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
+    } else {
+        sc->n_inner = hs.root < 0 ? 0 : (int32_t)hs.nodes.size();
+    }
     DevScene &v = sc->view;
     v.nodes = sc->nodes.p;
     v.light_area_sum = hs.light_area_sum;
-    v.qnodes = hs.qnodes.empty() ? nullptr : sc->qnodes.p;
+    v.qnodes = sc->qnodes.p;  // nullptr: the float nodes are traversed
     for (int k = 0; k < 3; ++k) {
         v.q_origin[k] = hs.q_origin[k];
         v.q_cell[k] = hs.q_cell[k];
@@ -903,7 +954,11 @@ int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out)
         v.dbg = sc->dbg.p;
     }
 #endif
-    sc->info.n_nodes = (int32_t)hs.nodes.size();
+    sc->info.build_ms = std::chrono::duration<double, std::milli>(t_upload - t_build).count() + gpu_build_ms;
+    sc->info.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_upload).count() - gpu_build_ms;
+    sc->info.builder = hs.builder;
+    sc->info.quantised = sc->qnodes.p ? 1 : 0;
+    sc->info.n_nodes = sc->n_inner;
     sc->info.bvh_height = hs.height;
     sc->info.n_lights = v.n_lights;
     sc->info.n_prims = hs.n_triangles + hs.n_objects;
@@ -956,7 +1011,9 @@ int mcpt_bvh_dump(const mcpt_scene_desc *desc, mcpt_bvh_info *info, float *boxes
     if (!desc || !info) return fail(MCPT_ERR_ARG, "mcpt_bvh_dump: null argument");
     HostScene hs;
     const char *err = "";
-    const int rc = build_host_scene(*desc, hs, &err);
+    const BuildChoice choice = resolve_build_choice(nullptr);
+    if (choice.builder == MCPT_BUILD_GPU_LBVH) return fail(MCPT_ERR_ARG, "mcpt_bvh_dump: the tree is built on the device (MCPT_BVH=lbvh): use mcpt_scene_dump_bvh");
+    const int rc = build_host_scene(*desc, hs, &err, choice);
     if (rc != MCPT_OK) return fail(rc, std::string("mcpt_bvh_dump: ") + err);
     std::memset(info, 0, sizeof *info);
     const bool placeholder = hs.root < 0;  // a single primitive: no inner node (the array holds one unused record)
@@ -988,6 +1045,51 @@ int mcpt_bvh_dump(const mcpt_scene_desc *desc, mcpt_bvh_info *info, float *boxes
             for (int w = 0; w < 6; ++w) {
                 q[2 * w] = (uint16_t)(Q.w[w] & 0xffffu);
                 q[2 * w + 1] = (uint16_t)(Q.w[w] >> 16);
+            }
+        }
+    }
+    return MCPT_OK;
+}
+
+int mcpt_scene_dump_bvh(mcpt_scene *sc, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes) {
+    if (!sc || !info) return fail(MCPT_ERR_ARG, "mcpt_scene_dump_bvh: null argument");
+    HIP_TRY(hipSetDevice(sc->device));
+    std::memset(info, 0, sizeof *info);
+    const DevScene &v = sc->view;
+    info->n_nodes = sc->n_inner;
+    info->root = v.root;
+    info->stack_entries = v.height;
+    info->quantised = v.qnodes ? 1 : 0;
+    for (int k = 0; k < 3; ++k) {
+        info->root_min[k] = v.root_min[k];
+        info->root_max[k] = v.root_max[k];
+        info->q_origin[k] = v.q_origin[k];
+        info->q_cell[k] = v.q_cell[k];
+    }
+    if (!boxes || !children || info->n_nodes == 0) return MCPT_OK;
+    std::vector<Node> nodes((size_t)info->n_nodes);
+    HIP_TRY(hipMemcpy(nodes.data(), sc->nodes.p, nodes.size() * sizeof(Node), hipMemcpyDeviceToHost));
+    std::vector<QNode> qn;
+    if (qboxes && info->quantised) {
+        qn.resize(nodes.size());
+        HIP_TRY(hipMemcpy(qn.data(), sc->qnodes.p, qn.size() * sizeof(QNode), hipMemcpyDeviceToHost));
+    }
+    for (int32_t i = 0; i < info->n_nodes; ++i) {
+        const Node &N = nodes[i];
+        float *b = boxes + (size_t)i * 12;
+        for (int k = 0; k < 3; ++k) {
+            b[k] = N.lmin[k];
+            b[3 + k] = N.lmax[k];
+            b[6 + k] = N.rmin[k];
+            b[9 + k] = N.rmax[k];
+        }
+        children[2 * i] = N.left;
+        children[2 * i + 1] = N.right;
+        if (!qn.empty()) {
+            uint16_t *q = qboxes + (size_t)i * 12;
+            for (int w = 0; w < 6; ++w) {
+                q[2 * w] = (uint16_t)(qn[i].w[w] & 0xffffu);
+                q[2 * w + 1] = (uint16_t)(qn[i].w[w] >> 16);
             }
         }
     }

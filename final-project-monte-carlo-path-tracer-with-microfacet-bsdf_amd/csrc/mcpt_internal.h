@@ -127,6 +127,8 @@ struct HostScene {
     int32_t root;                         // root child reference (inner index or leaf)
     int32_t n_triangles = 0, n_objects = 0;
     int32_t height = 0;
+    int32_t builder = 0;                  // 0 host binned SAH, 1 host reference topology, 2 GPU LBVH (mcpt_scene_info::builder)
+    std::vector<int32_t> sphere_objects;  // object index of every sphere object (the GPU builder's primitive list)
     float background[3];
     int32_t env_w = 0, env_h = 0;
     std::vector<float> env;
@@ -135,7 +137,15 @@ struct HostScene {
     float light_radius = 0.f;
 };
 
-// Builds the flattened scene.  Returns MCPT_OK or an error code and fills `err`.
-int build_host_scene(const mcpt_scene_desc &d, HostScene &out, const char **err);
+// Builder choice after the environment overrides have been applied (mcpt_build_options, include/mcpt.h).
+struct BuildChoice {
+    int32_t builder = MCPT_BUILD_SAH;  // MCPT_BUILD_SAH | MCPT_BUILD_REFERENCE | MCPT_BUILD_GPU_LBVH
+    int32_t quantise = -1;             // -1 automatic, 0 never, 1 always
+};
+BuildChoice resolve_build_choice(const mcpt_build_options *opt);
+
+// Builds the flattened scene.  Returns MCPT_OK or an error code and fills `err`.  With MCPT_BUILD_GPU_LBVH the traversal tree is left
+// out (nodes empty, root/height unset): the caller builds it on the device (csrc/mcpt_lbvh.hip); everything else is filled.
+int build_host_scene(const mcpt_scene_desc &d, HostScene &out, const char **err, const BuildChoice &choice);
 
 }  // namespace mcpt

@@ -1,0 +1,22 @@
+// GPU LBVH builder (csrc/mcpt_lbvh.hip): builds the traversal tree of a scene on the device.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mcpt_internal.h"
+
+namespace mcpt {
+
+struct LbvhResult {
+    int32_t root, height, n_nodes, quantised;
+    float root_min[3], root_max[3];
+    float q_origin[3], q_cell[3];
+};
+
+// d_tris: the caller's triangles (exact stored vertices) on the device; d_sphere_obj: object index of every sphere object;
+// d_spheres: SphereRec array indexed by object index.  Primitive ids: triangle index, or n_tri + object index for a sphere.
+// Needs n_tri + n_sph >= 2.  d_nodes / d_qnodes: n - 1 entries each, written by the build (d_qnodes may stay unused: see
+// LbvhResult::quantised).  quantise: -1 automatic, 0 never, 1 always.  Synchronises `st`.
+hipError_t build_lbvh_device(const mcpt_triangle *d_tris, int n_tri, const int32_t *d_sphere_obj, const SphereRec *d_spheres, int n_sph,
+                             int quantise, Node *d_nodes, QNode *d_qnodes, LbvhResult *out, hipStream_t st);
+
+}  // namespace mcpt

@@ -255,8 +255,34 @@ struct Flattener {
 
 }  // namespace
 
-int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) {
+BuildChoice resolve_build_choice(const mcpt_build_options *opt) {
+    BuildChoice c;
+    int builder = opt ? opt->builder : MCPT_BUILD_DEFAULT;
+    int quant = opt ? opt->quantise : -1;
+    if (builder == MCPT_BUILD_DEFAULT) {
+        const char *e = std::getenv("MCPT_BVH");
+        if (e && std::strcmp(e, "reference") == 0) builder = MCPT_BUILD_REFERENCE;
+        else if (e && std::strcmp(e, "lbvh") == 0) builder = MCPT_BUILD_GPU_LBVH;
+        else builder = MCPT_BUILD_SAH;
+    }
+    if (quant < 0) {
+        const char *q = std::getenv("MCPT_QUANT_NODES");
+        if (q && q[0] == '0') quant = 0;
+        else if (q && q[0] == '1') quant = 1;
+    }
+    c.builder = builder;
+    c.quantise = quant;
+    return c;
+}
+
+int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, const BuildChoice &choice) {
     *err = "";
+    if (choice.builder != MCPT_BUILD_SAH && choice.builder != MCPT_BUILD_REFERENCE && choice.builder != MCPT_BUILD_GPU_LBVH) {
+        *err = "unknown builder in mcpt_build_options";
+        return MCPT_ERR_ARG;
+    }
+    const bool gpu_build = choice.builder == MCPT_BUILD_GPU_LBVH;
+    const bool mesh_trees = choice.builder == MCPT_BUILD_REFERENCE;  // otherwise only emissive meshes need their own tree
     if (d.n_objects <= 0 || !d.objects || d.n_materials <= 0 || !d.materials || d.n_triangles < 0 ||
         (d.n_triangles > 0 && !d.triangles)) {
         *err = "scene description: empty or null arrays";
@@ -315,6 +341,7 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) 
             s.mat = o.material;
             s.mat_bits = (uint32_t)o.material | (hs.materials[o.material].hasEmission ? 0x80000000u : 0u);
             B.prim = d.n_triangles + oi;
+            hs.sphere_objects.push_back(oi);
             const V3 c = ld(o.center);
             B.bounds = box_pp({c.x - o.radius, c.y - o.radius, c.z - o.radius}, {c.x + o.radius, c.y + o.radius, c.z + o.radius});
             B.area = 4 * 3.141592653589793f * o.radius * o.radius;
@@ -378,20 +405,33 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) 
             B.prim = -1;
             B.bounds = box_pp(mn, mx);
             B.area = area;
-            B.mesh_root = recursive_build(arena, ptrs);
+            // the per-mesh tree (Triangle.hpp:134) carries the traversal topology of the reference AND the area tree its light
+            // sampling descends (BVH.cpp:118-129); with the GPU builder only emissive meshes still need it
+            B.mesh_root = (mesh_trees || hs.materials[o.material].hasEmission) ? recursive_build(arena, ptrs) : nullptr;
         } else {
             *err = "object kind out of range";
             return MCPT_ERR_ARG;
         }
     }
 
-    std::vector<BObj *> tops;
-    for (BObj &b : top_objs) tops.push_back(&b);
-    const BNode *root = recursive_build(arena, tops);  // Scene::buildBVH, Scene.cpp:14-17
-
-    // Default: the SAH tree.  MCPT_BVH=reference keeps the reference's two-level median-split topology.
-    const char *bvh_env = std::getenv("MCPT_BVH");
-    if (!(bvh_env && std::strcmp(bvh_env, "reference") == 0)) {
+    Flattener F{hs};
+    if (gpu_build) {
+        // the traversal tree is built on the device by the caller (csrc/mcpt_lbvh.hip); keep the device array non-empty
+        hs.builder = 2;
+        hs.root = 0;
+        hs.height = 0;
+        hs.nodes.clear();
+        hs.qnodes.clear();
+    } else {
+    const BNode *root = nullptr;
+    // Default: the SAH tree.  MCPT_BUILD_REFERENCE keeps the reference's two-level median-split topology.
+    if (choice.builder == MCPT_BUILD_REFERENCE) {
+        hs.builder = 1;
+        std::vector<BObj *> tops;
+        for (BObj &b : top_objs) tops.push_back(&b);
+        root = recursive_build(arena, tops);  // Scene::buildBVH, Scene.cpp:14-17
+    } else {
+        hs.builder = 0;
         std::vector<BObj *> prims;
         prims.reserve((size_t)d.n_triangles + d.n_objects);
         for (int oi = 0; oi < d.n_objects; ++oi) {
@@ -402,7 +442,6 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) 
         root = sah_build(arena, prims, 0, prims.size());
     }
 
-    Flattener F{hs};
     hs.nodes.reserve((size_t)d.n_triangles + d.n_objects + 8);
     hs.root = F.flatten(root, 1);
     hs.height = F.height;
@@ -415,8 +454,7 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) 
     // quantised nodes (see QNode).  Skipped when a grid cell would not be small against the primitives' boxes (a huge ground
     // plane in a scene of tiny triangles): inflated leaf boxes would cost more visits than the smaller nodes save.
     hs.qnodes.clear();
-    const char *qenv = std::getenv("MCPT_QUANT_NODES");
-    if (!hs.nodes.empty() && !(qenv && qenv[0] == '0')) {
+    if (!hs.nodes.empty() && choice.quantise != 0) {
         double origin[3], cell[3];
         const float rmn[3] = {root->bounds.mn.x, root->bounds.mn.y, root->bounds.mn.z};
         const float rmx[3] = {root->bounds.mx.x, root->bounds.mx.y, root->bounds.mx.z};
@@ -440,7 +478,7 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) 
         if (!diag.empty()) {
             std::nth_element(diag.begin(), diag.begin() + diag.size() / 2, diag.end());
             const double cd = std::sqrt(cell[0] * cell[0] + cell[1] * cell[1] + cell[2] * cell[2]);
-            ok = ok && (cd * 8.0 <= (double)diag[diag.size() / 2] || (qenv && qenv[0] == '1'));
+            ok = ok && (cd * 8.0 <= (double)diag[diag.size() / 2] || choice.quantise == 1);
         }
         if (ok) {
             // the device dequantises in float: x = q_origin + q * q_cell; one extra cell on each side covers its rounding
@@ -473,6 +511,7 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err) 
         hs.nodes[0].left = hs.nodes[0].right = kNoChild;
     }
 
+    }
     // light table, Scene.hpp:106-108 (insertion order)
     hs.light_area_sum = 0.f;
     for (int oi = 0; oi < d.n_objects; ++oi) {

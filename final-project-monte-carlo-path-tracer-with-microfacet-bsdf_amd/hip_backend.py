@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MCPT_LIB") or os.path.join(HERE, "libmcpt_hip.so")  #
 CHECK_LIB_PATH = os.path.join(HERE, "libmcpt_hip_check.so")  # the checking build (build.build_check); tests only
 
 EXPORTS = ["mcpt_scene_create", "mcpt_scene_destroy", "mcpt_render", "mcpt_render_device", "mcpt_intersect",
-           "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_bvh_dump", "mcpt_debug_fmath", "mcpt_debug_counters",
+           "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_bvh_dump", "mcpt_scene_create_ex", "mcpt_scene_dump_bvh", "mcpt_debug_fmath", "mcpt_debug_counters",
            "mcpt_group_create", "mcpt_group_render", "mcpt_group_size", "mcpt_group_destroy", "mcpt_group_last_error",
            "mcpt_last_error", "mcpt_version"]
 
@@ -53,9 +53,17 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class BuildOptions(C.Structure):
+    _fields_ = [("builder", C.c_int32), ("quantise", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
+BUILDERS = {"default": 0, "sah": 1, "reference": 2, "lbvh": 3}  # MCPT_BUILD_*
+
+
 class SceneInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("bvh_height", C.c_int32), ("n_lights", C.c_int32), ("n_prims", C.c_int32),
-                ("scene_bytes", C.c_uint64)]
+                ("scene_bytes", C.c_uint64), ("build_ms", C.c_double), ("upload_ms", C.c_double), ("builder", C.c_int32),
+                ("quantised", C.c_int32)]
 
 
 _libs = {}
@@ -72,6 +80,10 @@ def lib(path=None):
         L.mcpt_version.restype = C.c_char_p
         L.mcpt_scene_create.restype = C.c_int
         L.mcpt_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.mcpt_scene_create_ex.restype = C.c_int
+        L.mcpt_scene_create_ex.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mcpt_scene_dump_bvh.restype = C.c_int
+        L.mcpt_scene_dump_bvh.argtypes = [C.c_void_p, C.POINTER(BvhInfo), C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcpt_scene_destroy.restype = None
         L.mcpt_scene_destroy.argtypes = [C.c_void_p]
         L.mcpt_scene_get_info.restype = C.c_int
@@ -154,16 +166,31 @@ def bvh_dump(sd):
 class HipScene:
     """A scene resident in the HBM of one GPU (mcpt_scene_create)."""
 
-    def __init__(self, sd, device=-1, library=None):
-        """library: path of an alternative build of the same ABI (the checking build); None = the product library."""
+    def __init__(self, sd, device=-1, library=None, builder=None, quantise=-1):
+        """library: path of an alternative build of the same ABI (the checking build); None = the product library.
+        builder: None (mcpt_scene_create: environment / default) or "sah" | "reference" | "lbvh" (mcpt_scene_create_ex)."""
         self.sd = sd
         self._keep = []
         self.L = lib(library)
         d = _make_desc(sd, self._keep)
         h = C.c_void_p()
         self.h = None
-        _check(self.L.mcpt_scene_create(C.byref(d), int(device), C.byref(h)), L=self.L)
+        if builder is None and quantise == -1:
+            _check(self.L.mcpt_scene_create(C.byref(d), int(device), C.byref(h)), L=self.L)
+        else:
+            opt = BuildOptions(builder=BUILDERS[builder or "default"], quantise=int(quantise))
+            _check(self.L.mcpt_scene_create_ex(C.byref(d), int(device), C.byref(opt), C.byref(h)), L=self.L)
         self.h = h
+
+    def dump_bvh(self):
+        """The traversal tree as it sits in HBM: (info dict, boxes[n,12], children[n,2], qboxes[n,12] or None)."""
+        info = BvhInfo()
+        _check(self.L.mcpt_scene_dump_bvh(self.h, C.byref(info), None, None, None), L=self.L)
+        n = info.n_nodes
+        boxes, children, qboxes = np.zeros((n, 12), np.float32), np.zeros((n, 2), np.int32), np.zeros((n, 12), np.uint16)
+        _check(self.L.mcpt_scene_dump_bvh(self.h, C.byref(info), _ptr(boxes), _ptr(children), _ptr(qboxes)), L=self.L)
+        out = {k: (list(getattr(info, k)) if k in ("root_min", "root_max", "q_origin", "q_cell") else getattr(info, k)) for k, _ in info._fields_}
+        return out, boxes, children, (qboxes if info.quantised else None)
 
     def close(self):
         if getattr(self, "h", None):

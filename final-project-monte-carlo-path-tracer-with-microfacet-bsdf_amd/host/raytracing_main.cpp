@@ -4,6 +4,9 @@
 // renderer.path and renderer.parrallelism are ignored; addDiamond only has to be present; lightBrightness must be a
 // JSON float.  Additions: optional command-line overrides, because DEMO hard-codes 384x384 / spp 2048:
 //   --width N --height N --spp N --output FILE --conf FILE --models DIR
+//   --fixed       honour the keys the shipped main ignores: scene.directLightSample (Scene::setDirectLightSample, Scene.hpp:114),
+//                 scene.model_quality (low_* / high_* models; main.cpp:24-26 composes the paths before reading the key) and
+//                 scene.addDiamond:false (main.cpp:197-199 tests presence only)
 //   --gpus N      render on GPUs 0..N-1 (tile partition + RCCL merge inside the library); --devices 0,0 lists them explicitly
 //   --dump FILE   write the flattened scene (what mcpt_scene_create receives) and exit without touching the GPU
 #include <chrono>
@@ -36,6 +39,14 @@ int main(int argc, char **argv) {
 
     std::string models = "../models", conf_path = "conf.json", out_override, dump_path;
     int w_override = 0, h_override = 0, spp_override = 0;
+    bool fixed = false;
+    for (int i = 1; i < argc; ++i)
+        if (std::string(argv[i]) == "--fixed") {  // the only flag without a value: take it out of the (flag, value) list
+            fixed = true;
+            for (int k = i; k + 1 < argc; ++k) argv[k] = argv[k + 1];
+            --argc;
+            --i;
+        }
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string a = argv[i];
         if (a == "--width") w_override = std::atoi(argv[i + 1]);
@@ -58,7 +69,20 @@ int main(int argc, char **argv) {
         }
     }
     bool use_diamond = false;
-    const std::string model_quality = "low";  // the conf value is read after the paths are composed (main.cpp:24-26,200-202)
+    std::string model_quality = "low";  // the conf value is read after the paths are composed (main.cpp:24-26,200-202)
+#ifndef DEMO
+    if (fixed) {  // --fixed: read the key first, as its note in conf.json promises
+        try {
+            std::ifstream in(conf_path);
+            std::stringstream buf;
+            buf << in.rdbuf();
+            const Json pre = Json::parse(buf.str());
+            const Json &q = pre["scene"]["model_quality"];
+            if (q.is_string() && (q.as_string() == "low" || q.as_string() == "high")) model_quality = q.as_string();
+        } catch (const std::exception &) {
+        }
+    }
+#endif
     const std::string king_model = models + "/" + model_quality + "_king.obj";
     const std::string soldier_model = models + "/" + model_quality + "_soldier.obj";
 
@@ -102,6 +126,7 @@ int main(int argc, char **argv) {
     camera.focal_distance = 900;
     camera.aperture_radius = 40;
     (void)conf_path;
+    (void)fixed;
     (void)use_diamond;
     (void)king_model;
     (void)soldier_model;
@@ -134,7 +159,9 @@ int main(int argc, char **argv) {
         }
         const Json &cs = data["scene"];
         if (!cs.is_null()) {
-            if (cs["addDiamond"].is_boolean()) use_diamond = true;  // main.cpp:197-199
+            if (cs["addDiamond"].is_boolean()) use_diamond = fixed ? cs["addDiamond"].as_bool() : true;  // main.cpp:197-199
+            if (fixed && cs["directLightSample"].is_number() && cs["directLightSample"].as_int() > 0)
+                scene.setDirectLightSample(cs["directLightSample"].as_int());  // Scene.hpp:114 (no caller in the shipped main)
             if (cs["includeShadow"].is_boolean()) scene.enableShadow(cs["includeShadow"].as_bool());
             if (cs["RussianRouletteRate"].is_number()) scene.setRrRate(cs["RussianRouletteRate"].as_float());
             if (!cs["envMap"].is_null()) {
@@ -202,6 +229,7 @@ int main(int argc, char **argv) {
         out.write((const char *)&c, sizeof c);
         out.write((const char *)&p.rr_rate, sizeof(float));
         out.write((const char *)scene.backgroundColor.data(), 3 * sizeof(float));
+        out.write((const char *)&p.n_dir_sample, sizeof(int32_t));
         return out.good() ? 0 : 1;
     }
 

@@ -14,6 +14,10 @@ Reference behaviour mirrored (file:line are relative to /root/reference/src):
   * camera ............................... Camera.hpp:17-24, main.cpp:324-328
   * ignored conf keys .................... scene.directLightSample, scene.model_quality, renderer.path,
         renderer.parrallelism; scene.addDiamond only checks presence (main.cpp:191,197-202)
+  * chess_scene(fixed=True) ("--fixed" of host/RayTracing): the configuration as its keys READ instead of as the
+        shipped main executes it -- scene.directLightSample is applied (Scene::setDirectLightSample, Scene.hpp:114),
+        scene.model_quality selects low_*/high_* models (main.cpp:24-26 composes the paths before the key is read,
+        :200-202), scene.addDiamond:false leaves the diamond out (main.cpp:197-199 tests presence only).
 """
 from __future__ import annotations
 
@@ -277,7 +281,7 @@ def _is_v3(d):
     return isinstance(d, list) and len(d) == 3 and all(isinstance(e, (int, float)) and not isinstance(e, bool) for e in d)
 
 
-def chess_scene(conf=None, width=None, height=None, spp=None, assets=ASSETS, env_loader=None):
+def chess_scene(conf=None, width=None, height=None, spp=None, assets=ASSETS, env_loader=None, fixed=False):
     """The conf.json scene, main.cpp:131-328.  `conf` is a parsed conf.json (dict) or a path; None = the shipped
     conf.json with envMap replaced by its documented constant colour (sky.png is missing)."""
     if conf is None:
@@ -299,6 +303,8 @@ def chess_scene(conf=None, width=None, height=None, spp=None, assets=ASSETS, env
     light_pos, floor_mat, brightness = [0, 200, 0], "rough_plastic", 1.0
     use_diamond = False
     floor_textured = False
+    n_dir = 4  # Scene.hpp:28
+    quality = "low"  # main.cpp:24: the default, which the shipped executable never leaves
 
     cc = conf.get("camera")
     if cc is not None:
@@ -316,7 +322,9 @@ def chess_scene(conf=None, width=None, height=None, spp=None, assets=ASSETS, env
         out_spp = int(cr["spp"])
     cs = conf.get("scene")
     if cs is not None:
-        if isinstance(cs.get("addDiamond"), bool): use_diamond = True  # main.cpp:197-199: presence, not value
+        if isinstance(cs.get("addDiamond"), bool): use_diamond = cs["addDiamond"] if fixed else True  # main.cpp:197-199: presence, not value
+        if fixed and isinstance(cs.get("directLightSample"), int) and cs["directLightSample"] > 0: n_dir = int(cs["directLightSample"])
+        if fixed and cs.get("model_quality") in ("low", "high"): quality = cs["model_quality"]
         if isinstance(cs.get("includeShadow"), bool): shadow = cs["includeShadow"]
         if isinstance(cs.get("RussianRouletteRate"), (int, float)): rr = min(float(f32(cs["RussianRouletteRate"])), float(f32(0.99)))
         env = cs.get("envMap")
@@ -336,7 +344,7 @@ def chess_scene(conf=None, width=None, height=None, spp=None, assets=ASSETS, env
             xs, ys, zs = f32(cs["soldierXSpacing"]), f32(cs["soldierYSpacing"]), f32(cs["soldierZSpacing"])
             count = int(cs["soldierCountPerRow"])
             names = cs["soldierMaterials"]
-            soldier = os.path.join(assets, "low_soldier.obj")  # model_quality is ineffective, main.cpp:24-26
+            soldier = os.path.join(assets, quality + "_soldier.obj")  # (not fixed: model_quality is ineffective, main.cpp:24-26)
             for i in range(count):  # main.cpp:248-271
                 off = np.array([f32(i) * xs, f32(i) * ys, f32(i) * zs], dtype=f32)
                 lpos = (np.asarray(lrow, dtype=f32) + off).astype(f32)
@@ -353,7 +361,7 @@ def chess_scene(conf=None, width=None, height=None, spp=None, assets=ASSETS, env
     b.add_mesh(mesh_triangles(os.path.join(assets, "light.obj"), light_pos), b.material("light", light))
     b.add_mesh(mesh_triangles(os.path.join(assets, "bottom.obj"), textured=bool(P[floor_mat]["textured"])),
                b.material(floor_mat, P[floor_mat]))
-    b.add_mesh(mesh_triangles(os.path.join(assets, "low_king.obj"), king_pos), b.material(king_mat, P[king_mat]))
+    b.add_mesh(mesh_triangles(os.path.join(assets, quality + "_king.obj"), king_pos), b.material(king_mat, P[king_mat]))
     if use_diamond:
         b.add_mesh(mesh_triangles(os.path.join(assets, "diamond.obj")), b.material("smooth_glass_gem", P["smooth_glass_gem"]))
     if width is not None: w = width
@@ -361,4 +369,13 @@ def chess_scene(conf=None, width=None, height=None, spp=None, assets=ASSETS, env
     if spp is not None: out_spp = spp
     cam = make_camera(w, h, fov, cam_pos, cam_target, cam_up, use_dof, focal, aperture)
     return b.finish(camera=cam, rr_rate=rr, enable_shadow=shadow, spp=out_spp, background=background,
-                    env_pixels=env_pixels, name="chess")
+                    env_pixels=env_pixels, n_dir_sample=n_dir, name="chess" if quality == "low" else "chess_high")
+
+
+def chess_high(width=None, height=None, spp=None, n_dir=4, assets=ASSETS):
+    """The conf.json scene with model_quality "high" honoured (fixed mode): 296 274 triangles instead of 38 458.
+    n_dir stays a parameter (4 = what the shipped executable runs; conf.json says 32)."""
+    conf = json.loads(json.dumps(DEFAULT_CONF))
+    conf["scene"]["model_quality"] = "high"
+    conf["scene"]["directLightSample"] = int(n_dir)
+    return chess_scene(conf, width=width, height=height, spp=spp, assets=assets, fixed=True)

@@ -127,6 +127,22 @@ typedef struct mcpt_scene mcpt_scene;
 int mcpt_scene_create(const mcpt_scene_desc *desc, int device, mcpt_scene **out);
 void mcpt_scene_destroy(mcpt_scene *scene);
 
+/* The same with an explicit choice of the tree builder (mcpt_scene_create: options == NULL).  Closest-hit results do not depend on
+ * the tree (equal distances go to the larger primitive id); only rays that graze a box face within float rounding can differ.
+ *   MCPT_BUILD_SAH        host, binned SAH over all primitives (default)
+ *   MCPT_BUILD_REFERENCE  host, the reference's two-level median-split topology (BVH.cpp:27-93), flattened
+ *   MCPT_BUILD_GPU_LBVH   on the device: Morton-code linear BVH (radix sort + Karras hierarchy + bottom-up refit); milliseconds
+ *                         instead of seconds for large scenes, at a lower tree quality
+ * Fields left at MCPT_BUILD_DEFAULT / -1 take the environment overrides MCPT_BVH = sah | reference | lbvh and
+ * MCPT_QUANT_NODES = 0 | 1, then the defaults. */
+enum { MCPT_BUILD_DEFAULT = 0, MCPT_BUILD_SAH = 1, MCPT_BUILD_REFERENCE = 2, MCPT_BUILD_GPU_LBVH = 3 };
+typedef struct {
+    int32_t builder;  /* MCPT_BUILD_* */
+    int32_t quantise; /* -1 automatic, 0 float nodes (64 B), 1 quantised nodes (32 B) */
+    int32_t reserved[6];
+} mcpt_build_options;
+int mcpt_scene_create_ex(const mcpt_scene_desc *desc, int device, const mcpt_build_options *options, mcpt_scene **out);
+
 /* Replaces the pixel/spp loop of Renderer::Render (Renderer.cpp:21-91): fb_host = W*H*3 floats,
  * row-major m = j*W + i, linear radiance averaged over spp -- what `framebuffer` holds at Renderer.cpp:91.
  * Blocking.  Tone map and PNG output (Renderer.cpp:95-109) stay with the caller. */
@@ -171,6 +187,10 @@ const char *mcpt_group_last_error(void);
 typedef struct {
     int32_t n_nodes, bvh_height, n_lights, n_prims;
     uint64_t scene_bytes;
+    double build_ms;  /* flattening + BVH build (the data producer of BVHAccel::recursiveBuild, BVH.cpp:27-93) */
+    double upload_ms; /* host -> HBM copies */
+    int32_t builder;  /* 0 host binned SAH, 1 host reference topology (median split), 2 GPU LBVH */
+    int32_t quantised;/* 1: 32-byte nodes with 16-bit boxes are traversed */
 } mcpt_scene_info;
 int mcpt_scene_get_info(const mcpt_scene *scene, mcpt_scene_info *info);
 
@@ -187,6 +207,8 @@ typedef struct {
     float q_origin[3], q_cell[3]; /* grid coordinate q <-> q_origin + q * q_cell */
 } mcpt_bvh_info;
 int mcpt_bvh_dump(const mcpt_scene_desc *desc, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes);
+/* The same arrays downloaded from a live scene (whatever built its tree, the GPU builder included). */
+int mcpt_scene_dump_bvh(mcpt_scene *scene, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes);
 
 /* Diagnostic: evaluates the path's transcendental functions (csrc/mcpt_fmath.h: the library's own plain-IEEE sin / cos /
  * atan2 / acos, used where the reference calls libm at Material.hpp:117-118, Renderer.cpp:59-60, Sphere.hpp:66-67,

@@ -1,0 +1,81 @@
+"""The GPU BVH builder (csrc/mcpt_lbvh.hip, MCPT_BUILD_GPU_LBVH): the tree it leaves in HBM satisfies the invariants of the host
+builders' trees (tests/test_bvh_host.py: every primitive in exactly one leaf, child boxes contain what is below them, the
+declared stack bound covers the height, quantised boxes contain the exact ones), closest hits are bit-identical to the oracle's
+full traversal, and frames equal those rendered with the host-built SAH tree."""
+import numpy as np
+import pytest
+from test_bvh_host import check_tree
+
+pytestmark = pytest.mark.gpu
+
+
+def _soup(pkg, n=3000, seed=5, duplicates=True):
+    rng = np.random.default_rng(seed)
+    base = pkg.scenes.cornell_rc(32, 32, 1)
+    tri = np.zeros(n, dtype=base.triangles.dtype)
+    c = rng.uniform(-50, 50, (n, 3)).astype(np.float32)
+    if duplicates:  # many identical centroids: equal Morton codes, told apart by position only
+        c[n // 2:] = c[n // 2]
+    off = rng.normal(0, 0.5, (3, n, 3)).astype(np.float32)
+    off[2] = -(off[0] + off[1])  # the three offsets sum to zero: the centroid of the box stays near c
+    for k, name in enumerate(("v0", "v1", "v2")):
+        tri[name] = c + off[k]
+    obj = np.zeros(1, dtype=base.objects.dtype)
+    obj["kind"], obj["material"], obj["first_tri"], obj["n_tri"] = 0, 0, 0, n
+    return pkg.scenes.SceneData(triangles=tri, materials=base.materials[:1].copy(), objects=obj, background=base.background,
+                                env_pixels=None, camera=base.camera, rr_rate=base.rr_rate)
+
+
+@pytest.mark.parametrize("name", ["cornell_demo", "chess", "soup", "chess_high"])
+def test_gpu_built_tree_invariants_and_hits(pkg, oracle, hip, name, capsys):
+    sd = {"cornell_demo": lambda: pkg.scenes.cornell_demo(64, 64, 2), "chess": lambda: pkg.scenes.chess_scene(width=160, height=90, spp=2),
+          "soup": lambda: _soup(pkg), "chess_high": lambda: pkg.scenes.chess_high(160, 90, 2)}[name]()
+    hs = hip.HipScene(sd, builder="lbvh")
+    info, boxes, children, qboxes = hs.dump_bvh()
+    n_prims = len(sd.triangles) + int((sd.objects["kind"] == 1).sum())
+    assert info["n_nodes"] == n_prims - 1 == len(boxes)
+    h = check_tree(sd, info, boxes, children, qboxes)
+    meta = hs.info()
+    assert meta["builder"] == 2 and meta["bvh_height"] == info["stack_entries"] and h + 1 == info["stack_entries"]
+    sah = hip.HipScene(sd, builder="sah").info()
+    with capsys.disabled():
+        print("\n[lbvh] %-12s %7d prims: GPU build %.2f ms (height %d, quantised %d)  |  host SAH build %.1f ms (height %d)"
+              % (name, n_prims, meta["build_ms"], meta["bvh_height"], meta["quantised"], sah["build_ms"], sah["bvh_height"]))
+    # closest hits against the oracle's full traversal of the reference's tree: bit-exact
+    rng = np.random.default_rng(3)
+    n = 20000
+    lo, hi = np.array(info["root_min"], np.float32), np.array(info["root_max"], np.float32)
+    o = rng.uniform(lo - 0.2 * (hi - lo), hi + 0.2 * (hi - lo), size=(n, 3)).astype(np.float32)
+    tgt = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    t_ref, p_ref = oracle.OracleScene(sd).intersect(o, d)
+    t_gpu, p_gpu = hs.intersect(o, d)
+    assert np.array_equal(p_ref, p_gpu), "primitive ids differ on %d rays" % int((p_ref != p_gpu).sum())
+    assert np.array_equal(t_ref.view(np.uint64), t_gpu.view(np.uint64))
+    assert (p_ref >= 0).mean() > (0.02 if name == "soup" else 0.2)
+
+
+@pytest.mark.parametrize("name", ["cornell_demo", "chess"])
+def test_frames_do_not_depend_on_the_builder(pkg, hip, name):
+    sd = pkg.scenes.cornell_demo(96, 96, 8) if name == "cornell_demo" else pkg.scenes.chess_scene(width=240, height=135, spp=8)
+    ref, st0 = hip.HipScene(sd, builder="sah").render(spp=8, seed=6)
+    for builder, quant in (("lbvh", -1), ("lbvh", 0), ("reference", -1)):
+        fb, st = hip.HipScene(sd, builder=builder, quantise=quant).render(spp=8, seed=6)
+        differing = int((~((fb == ref) | (np.isnan(fb) & np.isnan(ref)))).sum())
+        assert differing <= 3, (builder, quant, differing)  # (a box-grazing ray may take another branch)
+        assert abs(int(st.vertices) - int(st0.vertices)) <= 3
+
+
+def test_single_primitive_and_options_errors(pkg, hip):
+    sd = _soup(pkg, n=1, duplicates=False)
+    hs = hip.HipScene(sd, builder="lbvh")  # no inner node: nothing to build on the device
+    assert hs.info()["n_nodes"] == 0
+    t, p = hs.intersect(np.float32([[0, 0, -200]]), np.float32([[0, 0, 1]]))
+    assert p[0] in (-1, 0)
+    import ctypes as C
+    opt = hip.BuildOptions(builder=9, quantise=-1)
+    keep = []
+    d = hip._make_desc(sd, keep)
+    h = C.c_void_p()
+    assert hip.lib().mcpt_scene_create_ex(C.byref(d), -1, C.byref(opt), C.byref(h)) == 1

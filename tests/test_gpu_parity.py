@@ -114,7 +114,7 @@ def test_cast_rays_parity(pkg, oracle, hip, name, tree_env, capsys):
     exact = hip.HipScene(sd).cast_rays(o, d, pix, smp, ch, seed=9)
     bad = ~_same_bits(ref, exact)
     assert not bad.any(), "reference tree: %d of %d paths differ, e.g. %s vs %s" % (bad.sum(), n, ref[bad][:4], exact[bad][:4])
-    for tree in [("sah", None), ("sah", "0"), ("reference", "1")]:
+    for tree in [("sah", None), ("sah", "0"), ("reference", "1"), ("lbvh", None)]:
         tree_env(*tree)
         gpu = hip.HipScene(sd).cast_rays(o, d, pix, smp, ch, seed=9)
         bad = ~_same_bits(ref, gpu)

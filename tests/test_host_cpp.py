@@ -28,7 +28,8 @@ def _read_dump(path, pkg):
     objs = np.frombuffer(raw, s.OBJ_DTYPE, no, off); off += no * 32
     cam = np.frombuffer(raw, s.CAM_DTYPE, 1, off)[0]; off += 72
     rr = np.frombuffer(raw, np.float32, 1, off)[0]; off += 4
-    bg = np.frombuffer(raw, np.float32, 3, off)
+    bg = np.frombuffer(raw, np.float32, 3, off); off += 12
+    _read_dump.n_dir = int(np.frombuffer(raw, np.int32, 1, off)[0])
     return tris, mats, objs, cam, rr, bg, env
 
 
@@ -80,6 +81,27 @@ def test_conf_quirks_in_cpp_host(pkg, host_bins, tmp_path):
     assert p.returncode == 0 and "Error when reading json config" in p.stderr
     tris, mats, objs, cam, rr, bg, env = _read_dump(out, pkg)
     assert len(objs) == 3 and int(cam["width"]) == 384  # light, floor, king with default materials
+
+
+def test_fixed_mode_honours_the_ignored_keys(pkg, host_bins, tmp_path):
+    """--fixed / chess_scene(fixed=True): directLightSample, model_quality and addDiamond:false take effect
+    (the shipped main ignores them: Scene.hpp:114 has no caller, main.cpp:24-26 vs :200-202, main.cpp:197-199)."""
+    conf = json.loads(json.dumps(pkg.scenes.DEFAULT_CONF))
+    conf["scene"]["model_quality"] = "high"
+    conf["scene"]["addDiamond"] = False
+    conf["scene"]["directLightSample"] = 16
+    (tmp_path / "conf.json").write_text(json.dumps(conf))
+    out = str(tmp_path / "fixed.bin")
+    subprocess.check_call([host_bins[0], "--fixed", "--models", MODELS, "--dump", out], cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    tris, mats, objs, cam, rr, bg, env = _read_dump(out, pkg)
+    sd = pkg.scenes.chess_scene(conf, fixed=True)
+    assert len(tris) == 9248 + 14 * 20480 + 2 + 2 and len(objs) == 17  # high_king, 14 high_soldier, floor, light; no diamond
+    assert _same(tris, sd.triangles) and _same(mats, sd.materials) and _same(objs, sd.objects)
+    assert _read_dump.n_dir == 16 == sd.n_dir_sample and sd.name == "chess_high"
+    # without --fixed the same file gives the shipped behaviour
+    subprocess.check_call([host_bins[0], "--models", MODELS, "--dump", out], cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    tris, mats, objs, cam, rr, bg, env = _read_dump(out, pkg)
+    assert len(tris) == 38458 and len(objs) == 18 and _read_dump.n_dir == 4
 
 
 @pytest.mark.gpu
