@@ -1235,6 +1235,30 @@ int mcpt_camera_rays(mcpt_scene *sc, const mcpt_camera *cam, uint32_t seed, int6
     return MCPT_OK;
 }
 
+int mcpt_tonemap_device(mcpt_scene *sc, const float *fb_device, int64_t n_pixels, uint8_t *rgba_device, void *hip_stream) {
+    if (!sc || n_pixels < 0 || (n_pixels > 0 && (!fb_device || !rgba_device))) return fail(MCPT_ERR_ARG, "mcpt_tonemap_device: bad argument");
+    if (n_pixels > 0x7fffffff) return fail(MCPT_ERR_ARG, "mcpt_tonemap_device: frame too large");
+    HIP_TRY(hipSetDevice(sc->device));
+    launch_tonemap(fb_device, (uint32_t)n_pixels, rgba_device, (hipStream_t)hip_stream);
+    HIP_TRY(hipGetLastError());
+    return MCPT_OK;
+}
+
+int mcpt_tonemap(mcpt_scene *sc, const float *fb_host, int64_t n_pixels, uint8_t *rgba_host) {
+    if (!sc || n_pixels < 0 || (n_pixels > 0 && (!fb_host || !rgba_host))) return fail(MCPT_ERR_ARG, "mcpt_tonemap: bad argument");
+    if (n_pixels == 0) return MCPT_OK;
+    if (n_pixels > 0x7fffffff) return fail(MCPT_ERR_ARG, "mcpt_tonemap: frame too large");
+    HIP_TRY(hipSetDevice(sc->device));
+    DevBuf<float> fb;
+    DevBuf<uint8_t> out;
+    HIP_TRY(fb.alloc((size_t)n_pixels * 3));
+    HIP_TRY(out.alloc((size_t)n_pixels * 4));
+    HIP_TRY(hipMemcpy(fb.p, fb_host, (size_t)n_pixels * 3 * sizeof(float), hipMemcpyHostToDevice));
+    launch_tonemap(fb.p, (uint32_t)n_pixels, out.p, nullptr);
+    HIP_TRY(hipMemcpy(rgba_host, out.p, (size_t)n_pixels * 4, hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
 int mcpt_debug_counters(mcpt_scene *sc, uint64_t out[16]) {
     if (!sc || !out) return fail(MCPT_ERR_ARG, "mcpt_debug_counters: null argument");
     std::memset(out, 0, 16 * sizeof(uint64_t));
@@ -1248,7 +1272,7 @@ int mcpt_debug_counters(mcpt_scene *sc, uint64_t out[16]) {
 }
 
 int mcpt_debug_fmath(mcpt_scene *sc, int kind, int64_t n, const float *x, const float *y, float *out) {
-    if (!sc || kind < 0 || kind > 3 || n < 0 || (n > 0 && (!x || !out || (kind == 2 && !y)))) return fail(MCPT_ERR_ARG, "mcpt_debug_fmath: bad argument");
+    if (!sc || kind < 0 || kind > 5 || n < 0 || (n > 0 && (!x || !out || ((kind == 2 || kind == 4) && !y)))) return fail(MCPT_ERR_ARG, "mcpt_debug_fmath: bad argument");
     if (n == 0) return MCPT_OK;
     if (n > 0x7fffffff) return fail(MCPT_ERR_ARG, "mcpt_debug_fmath: too many values for one call");
     HIP_TRY(hipSetDevice(sc->device));

@@ -121,6 +121,8 @@ void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, 
 // Multi-GPU merge helpers (csrc/mcpt_multi.hip): zero the pixels rank `rank` does not own (tile rule of mcpt_params); a += b.
 void launch_mask_unowned(float *fb, int width, int height, int tile, int rank, int nranks, hipStream_t s);
 void launch_add_frame(float *a, const float *b, uint32_t n, hipStream_t s);
+// Tone map of Renderer.cpp:95-103: n_pix RGB float triples -> n_pix RGBA8 (csrc/mcpt_fmath.h: mcpt_tonemap_byte).
+void launch_tonemap(const float *fb, uint32_t n_pix, unsigned char *rgba, hipStream_t s);
 void launch_debug_fmath(int kind, uint32_t n, const float *x, const float *y, float *out, hipStream_t s);
 void launch_accumulate(const float *result, const uint32_t *pixel_list, uint32_t n_pix, int32_t s_pass, float spp_total,
                        float *fb, hipStream_t s);

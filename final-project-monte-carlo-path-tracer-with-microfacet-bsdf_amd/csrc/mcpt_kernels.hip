@@ -974,8 +974,17 @@ __global__ __launch_bounds__(kBlock) void k_debug_fmath(int kind, uint32_t n, co
     case 0: mcpt_sincosf(x[i], &s, &c); out[i] = s; break;
     case 1: mcpt_sincosf(x[i], &s, &c); out[i] = c; break;
     case 2: out[i] = mcpt_atan2f(x[i], y[i]); break;
-    default: out[i] = mcpt_acosf(x[i]); break;
+    case 3: out[i] = mcpt_acosf(x[i]); break;
+    case 4: out[i] = mcpt_powf(x[i], y[i]); break;
+    default: out[i] = (float)mcpt_tonemap_byte(x[i]); break;
     }
+}
+
+// Renderer.cpp:95-103 on the device: one lane per pixel, RGBA8 out (alpha 255).
+__global__ __launch_bounds__(kBlock) void k_tonemap(const float *__restrict__ fb, uint32_t n_pix, uchar4 *__restrict__ rgba) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_pix) return;
+    rgba[i] = make_uchar4(mcpt_tonemap_byte(fb[(size_t)i * 3]), mcpt_tonemap_byte(fb[(size_t)i * 3 + 1]), mcpt_tonemap_byte(fb[(size_t)i * 3 + 2]), 255);
 }
 
 inline uint32_t blocks(uint32_t n) { return (n + kBlock - 1) / kBlock; }
@@ -1087,6 +1096,11 @@ void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, 
                   hipStream_t s) {
     if (n_cur_max == 0) return;
     hipLaunchKernelGGL(k_shade, dim3((n_cur_max + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, s, S, C, cur, next, X, cur_idx);
+}
+
+void launch_tonemap(const float *fb, uint32_t n_pix, unsigned char *rgba, hipStream_t s) {
+    if (n_pix == 0) return;
+    hipLaunchKernelGGL(k_tonemap, dim3(blocks(n_pix)), dim3(kBlock), 0, s, fb, n_pix, reinterpret_cast<uchar4 *>(rgba));
 }
 
 void launch_mask_unowned(float *fb, int width, int height, int tile, int rank, int nranks, hipStream_t s) {

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MCPT_LIB") or os.path.join(HERE, "libmcpt_hip.so")  #
 CHECK_LIB_PATH = os.path.join(HERE, "libmcpt_hip_check.so")  # the checking build (build.build_check); tests only
 
 EXPORTS = ["mcpt_scene_create", "mcpt_scene_destroy", "mcpt_render", "mcpt_render_device", "mcpt_intersect",
-           "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_bvh_dump", "mcpt_scene_create_ex", "mcpt_scene_dump_bvh", "mcpt_debug_fmath", "mcpt_debug_counters",
+           "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_bvh_dump", "mcpt_scene_create_ex", "mcpt_scene_dump_bvh", "mcpt_tonemap", "mcpt_tonemap_device", "mcpt_debug_fmath", "mcpt_debug_counters",
            "mcpt_group_create", "mcpt_group_render", "mcpt_group_size", "mcpt_group_destroy", "mcpt_group_last_error",
            "mcpt_last_error", "mcpt_version"]
 
@@ -84,6 +84,10 @@ def lib(path=None):
         L.mcpt_scene_create_ex.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.mcpt_scene_dump_bvh.restype = C.c_int
         L.mcpt_scene_dump_bvh.argtypes = [C.c_void_p, C.POINTER(BvhInfo), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcpt_tonemap.restype = C.c_int
+        L.mcpt_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.mcpt_tonemap_device.restype = C.c_int
+        L.mcpt_tonemap_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.mcpt_scene_destroy.restype = None
         L.mcpt_scene_destroy.argtypes = [C.c_void_p]
         L.mcpt_scene_get_info.restype = C.c_int
@@ -196,6 +200,13 @@ class HipScene:
         if getattr(self, "h", None):
             self.L.mcpt_scene_destroy(self.h)
             self.h = None
+
+    def tonemap(self, fb):
+        """Renderer.cpp:95-103 on the GPU: (H, W, 3) float32 -> (H, W, 4) uint8."""
+        fb = np.ascontiguousarray(fb, dtype=np.float32)
+        out = np.zeros(fb.shape[:-1] + (4,), dtype=np.uint8)
+        _check(self.L.mcpt_tonemap(self.h, _ptr(fb), fb.size // 3, _ptr(out)), L=self.L)
+        return out
 
     def debug_counters(self):
         out = np.zeros(16, dtype=np.uint64)
@@ -323,7 +334,7 @@ def debug_fmath(kind, x, y=None):
     if _FMATH_SCENE is None:
         from . import scenes
         _FMATH_SCENE = HipScene(scenes.cornell_rc(8, 8, 1))
-    k = {"sin": 0, "cos": 1, "atan2": 2, "acos": 3}[kind]
+    k = {"sin": 0, "cos": 1, "atan2": 2, "acos": 3, "pow": 4, "tonemap": 5}[kind]
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float32)
     out = np.zeros_like(x)

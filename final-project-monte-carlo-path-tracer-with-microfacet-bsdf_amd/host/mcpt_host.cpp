@@ -231,6 +231,69 @@ float Scene::castRay(const Ray &ray, int depth, const WaveLenType &wavelen) cons
 }
 
 // ------------------------------------------------------------------------------------------------ Renderer
+namespace {
+
+struct CheckpointHeader {
+    char magic[8];
+    int32_t width, height, spp_total, spp_done;
+    uint32_t seed;
+    int32_t n_dir;
+    float rr_rate;
+    uint32_t scene_hash;
+};
+
+uint32_t fnv1a(const void *data, size_t n, uint32_t h) {
+    const unsigned char *p = (const unsigned char *)data;
+    for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 16777619u;
+    return h;
+}
+
+uint32_t scene_hash(const Scene &scene) {
+    std::vector<mcpt_triangle> tris;
+    std::vector<mcpt_material> mats;
+    std::vector<mcpt_object> objs;
+    scene.flatten(tris, mats, objs);
+    const mcpt_camera c = scene.cameraDesc();
+    uint32_t h = 2166136261u;
+    h = fnv1a(tris.data(), tris.size() * sizeof(mcpt_triangle), h);
+    h = fnv1a(mats.data(), mats.size() * sizeof(mcpt_material), h);
+    h = fnv1a(objs.data(), objs.size() * sizeof(mcpt_object), h);
+    h = fnv1a(&c, sizeof c, h);
+    h = fnv1a(scene.backgroundColor.data(), 3 * sizeof(float), h);
+    return h;
+}
+
+bool load_checkpoint(const std::string &file, const CheckpointHeader &want, std::vector<float> &fb, int &spp_done) {
+    std::ifstream in(file, std::ios::binary);
+    if (!in) return false;
+    CheckpointHeader h{};
+    in.read((char *)&h, sizeof h);
+    if (!in || std::memcmp(h.magic, want.magic, 8) != 0 || h.width != want.width || h.height != want.height || h.spp_total != want.spp_total ||
+        h.seed != want.seed || h.n_dir != want.n_dir || h.rr_rate != want.rr_rate || h.scene_hash != want.scene_hash || h.spp_done <= 0 ||
+        h.spp_done > h.spp_total)
+        return false;
+    std::vector<float> tmp(fb.size());
+    in.read((char *)tmp.data(), (std::streamsize)(tmp.size() * sizeof(float)));
+    if (!in) return false;
+    fb.swap(tmp);
+    spp_done = h.spp_done;
+    return true;
+}
+
+bool save_checkpoint(const std::string &file, CheckpointHeader h, const std::vector<float> &fb, int spp_done) {
+    h.spp_done = spp_done;
+    const std::string tmp = file + ".tmp";
+    {
+        std::ofstream out(tmp, std::ios::binary | std::ios::trunc);
+        out.write((const char *)&h, sizeof h);
+        out.write((const char *)fb.data(), (std::streamsize)(fb.size() * sizeof(float)));
+        if (!out) return false;
+    }
+    return std::rename(tmp.c_str(), file.c_str()) == 0;  // atomic replacement: a crash never leaves half a file under the name
+}
+
+}  // namespace
+
 void Renderer::Render(const Scene &scene) {
     const Camera &camera = scene.camera;
     std::vector<float> framebuffer((size_t)camera.width * camera.height * 3, 0.f);
@@ -240,19 +303,64 @@ void Renderer::Render(const Scene &scene) {
         return;
     }
     const mcpt_camera c = scene.cameraDesc();
-    const mcpt_params p = scene.params(spp);
-    mcpt_stats st{};
-    // Renderer.cpp:36-90
-    const int rc = scene.groupHandle() ? mcpt_group_render(scene.groupHandle(), &c, &p, framebuffer.data(), &st)
-                                       : mcpt_render(scene.handle(), &c, &p, framebuffer.data(), &st);
-    if (rc != MCPT_OK) std::cerr << "mcpt: " << (scene.groupHandle() ? mcpt_group_last_error() : mcpt_last_error()) << std::endl;
-    if (rc != MCPT_OK && rc != MCPT_ERR_OVERFLOW) return;
+    mcpt_params p = scene.params(spp);
+    mcpt_stats st{}, total{};
+    auto render = [&](const mcpt_params &q) {  // Renderer.cpp:36-90
+        const int rc = scene.groupHandle() ? mcpt_group_render(scene.groupHandle(), &c, &q, framebuffer.data(), &st)
+                                           : mcpt_render(scene.handle(), &c, &q, framebuffer.data(), &st);
+        if (rc != MCPT_OK) std::cerr << "mcpt: " << (scene.groupHandle() ? mcpt_group_last_error() : mcpt_last_error()) << std::endl;
+        total.samples += st.samples;
+        total.iterations += st.iterations;
+        total.ms_total += st.ms_total;
+        return rc;
+    };
+    if (checkpoint_path.empty()) {
+        const int rc = render(p);
+        if (rc != MCPT_OK && rc != MCPT_ERR_OVERFLOW) return;
+    } else {
+        CheckpointHeader h{};
+        std::memcpy(h.magic, "MCPTCKP1", 8);
+        h.width = camera.width;
+        h.height = camera.height;
+        h.spp_total = spp;
+        h.seed = p.seed;
+        h.n_dir = p.n_dir_sample;
+        h.rr_rate = p.rr_rate;
+        h.scene_hash = scene_hash(scene);
+        int done = 0;
+        if (load_checkpoint(checkpoint_path, h, framebuffer, done))
+            std::cout << "[mcpt] resuming from " << checkpoint_path << " at " << done << " of " << spp << " spp" << std::endl;
+        const int every = checkpoint_every > 0 ? checkpoint_every : spp;
+        while (done < spp) {
+            mcpt_params q = p;
+            q.spp = std::min(every, spp - done);
+            q.spp_total = spp;
+            q.sample_offset = done;
+            q.accumulate = done > 0 ? 1 : 0;
+            const int rc = render(q);
+            if (rc != MCPT_OK && rc != MCPT_ERR_OVERFLOW) return;
+            done += q.spp;
+            if (!save_checkpoint(checkpoint_path, h, framebuffer, done)) std::cerr << "mcpt: cannot write checkpoint " << checkpoint_path << std::endl;
+            if (stop_after > 0 && done >= stop_after && done < spp) {
+                std::cout << "[mcpt] stopped after " << done << " spp (checkpoint kept)" << std::endl;
+                return;
+            }
+        }
+    }
+    st = total;
     std::cout << "[mcpt] " << st.samples / 1e6 << " Msamples in " << st.ms_total << " ms = "
               << (st.ms_total > 0 ? st.samples / st.ms_total / 1e3 : 0.0) << " Msamples/s, " << st.iterations
               << " wavefront iterations" << (scene.groupHandle() ? " on " + std::to_string(mcpt_group_size(scene.groupHandle())) + " GPU replicas" : std::string()) << std::endl;
 
     std::cout << "Writing image to " << path << std::endl;
     std::vector<unsigned char> raw((size_t)4 * camera.width * camera.height);
+    // Renderer.cpp:95-103 on the GPU (mcpt_tonemap); the loop below is the reference's own, kept as the path taken if that call fails
+    if (mcpt_tonemap(scene.handle(), framebuffer.data(), (int64_t)camera.width * camera.height, raw.data()) == MCPT_OK) {
+        const std::string err = png_min::encode_rgba(path, raw, camera.width, camera.height);
+        if (!err.empty()) std::cerr << "Error when writing image : " << err << std::endl;
+        return;
+    }
+    std::cerr << "mcpt: " << mcpt_last_error() << std::endl;
     const float inv_gamma = 0.45f;
     auto clamp255 = [](float v) {  // clamp(0, 255, v) with std::min/std::max semantics: NaN -> 255 (global.hpp:16-18)
         const float a = (v < 255.f) ? v : 255.f;

@@ -250,6 +250,13 @@ class Renderer {
     void Render(const Scene &scene);
     void setSpp(int s) { spp = s; }
     std::string path = "./output.png";
+    // Pass-wise accumulation with a checkpoint file (the reference's render is all-or-nothing: two hours, Renderer.cpp:36-90).
+    // With a checkpoint path the frame is rendered in chunks of `checkpoint_every` spp (mcpt_params.sample_offset / accumulate:
+    // the same Philox keys and the same order of additions as one call, so the image is bit-identical), the running frame is
+    // written after every chunk, and a later run with the same scene, size, spp and seed continues where the file stops.
+    std::string checkpoint_path;
+    int checkpoint_every = 64;
+    int stop_after = 0;  // test hook: leave after this many spp have been rendered in total (simulates an interruption)
 
   private:
     int spp = 2048;

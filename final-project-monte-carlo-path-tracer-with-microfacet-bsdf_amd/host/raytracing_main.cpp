@@ -8,6 +8,7 @@
 //                 scene.model_quality (low_* / high_* models; main.cpp:24-26 composes the paths before reading the key) and
 //                 scene.addDiamond:false (main.cpp:197-199 tests presence only)
 //   --gpus N      render on GPUs 0..N-1 (tile partition + RCCL merge inside the library); --devices 0,0 lists them explicitly
+//   --checkpoint FILE [--checkpoint-every N]   render in chunks of N spp (default 64), keep the running frame in FILE and resume from it
 //   --dump FILE   write the flattened scene (what mcpt_scene_create receives) and exit without touching the GPU
 #include <chrono>
 #include <cstring>
@@ -56,6 +57,9 @@ int main(int argc, char **argv) {
         else if (a == "--conf") conf_path = argv[i + 1];
         else if (a == "--models") models = argv[i + 1];
         else if (a == "--dump") dump_path = argv[i + 1];
+        else if (a == "--checkpoint") r.checkpoint_path = argv[i + 1];
+        else if (a == "--checkpoint-every") r.checkpoint_every = std::atoi(argv[i + 1]);
+        else if (a == "--stop-after") r.stop_after = std::atoi(argv[i + 1]);
         else if (a == "--gpus") {
             std::vector<int> dev;
             for (int k = 0; k < std::atoi(argv[i + 1]); ++k) dev.push_back(k);

@@ -169,6 +169,12 @@ int mcpt_cast_rays(mcpt_scene *scene, const mcpt_params *params, int64_t n, cons
 int mcpt_camera_rays(mcpt_scene *scene, const mcpt_camera *camera, uint32_t seed, int64_t n, const uint32_t *pixel,
                      const uint32_t *sample, float *origins, float *dirs);
 
+/* Tone map of Renderer.cpp:95-103 on the GPU: rgba[4i + c] = (unsigned char) clamp(0, 255, 255 * pow(fb[3i + c], 0.45f)), alpha 255,
+ * NaN -> 255 as the reference's std::min/std::max clamp gives.  std::pow is the library's own plain-IEEE pow (csrc/mcpt_fmath.h), within
+ * an ulp of any libm's.  Optional: the float frame of mcpt_render is the boundary's product; callers may keep their own tone map. */
+int mcpt_tonemap(mcpt_scene *scene, const float *fb_host, int64_t n_pixels, uint8_t *rgba_host);
+int mcpt_tonemap_device(mcpt_scene *scene, const float *fb_device, int64_t n_pixels, uint8_t *rgba_device, void *hip_stream);
+
 /* ---- Multi-GPU inside the boundary.  The caller stays single-threaded like the reference's main() (Renderer::Render blocks,
  * main.cpp:333): a group holds one replica of the scene per device; mcpt_group_render partitions the frame into interleaved
  * tiles over the devices (tile_size of `params`, default 32; its rank/nranks fields are ignored), drives every device from its
@@ -213,7 +219,8 @@ int mcpt_scene_dump_bvh(mcpt_scene *scene, mcpt_bvh_info *info, float *boxes, in
 /* Diagnostic: evaluates the path's transcendental functions (csrc/mcpt_fmath.h: the library's own plain-IEEE sin / cos /
  * atan2 / acos, used where the reference calls libm at Material.hpp:117-118, Renderer.cpp:59-60, Sphere.hpp:66-67,
  * Scene.hpp:66-67) ON THE DEVICE for n host floats, so that tests can check that kernels and a CPU build of the same
- * header agree bit for bit.  kind: 0 sin(x), 1 cos(x), 2 atan2(x, y), 3 acos(x); y may be NULL unless kind == 2. */
+ * header agree bit for bit.  kind: 0 sin(x), 1 cos(x), 2 atan2(x, y), 3 acos(x), 4 pow(x, y), 5 tone-map byte of x (as a float);
+ * y may be NULL unless kind is 2 or 4. */
 int mcpt_debug_fmath(mcpt_scene *scene, int kind, int64_t n, const float *x, const float *y, float *out);
 
 /* Diagnostic: counters of the checking build (libmcpt_hip_check.so, compiled with -DMCPT_CHECK_DIRECT_SKIP; the traversal

@@ -1083,7 +1083,7 @@ void orc_material_refract(const orc_material *sm, const float *I, const float *N
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 
-/* mcpt_fmath.h entry points for tests/test_fmath.py: kind 0 sin, 1 cos, 2 atan2(x, y), 3 acos */
+/* mcpt_fmath.h entry points for tests/test_fmath.py: kind 0 sin, 1 cos, 2 atan2(x, y), 3 acos, 4 pow(x, y), 5 tone-map byte */
 void orc_fmath(int kind, int64_t n, const float *x, const float *y, float *out) {
     for (int64_t i = 0; i < n; ++i) {
         float s, c;
@@ -1091,7 +1091,9 @@ void orc_fmath(int kind, int64_t n, const float *x, const float *y, float *out) 
         case 0: mcpt_sincosf(x[i], &s, &c); out[i] = s; break;
         case 1: mcpt_sincosf(x[i], &s, &c); out[i] = c; break;
         case 2: out[i] = mcpt_atan2f(x[i], y[i]); break;
-        default: out[i] = mcpt_acosf(x[i]); break;
+        case 3: out[i] = mcpt_acosf(x[i]); break;
+        case 4: out[i] = mcpt_powf(x[i], y[i]); break;
+        default: out[i] = (float)mcpt_tonemap_byte(x[i]); break;
         }
     }
 }

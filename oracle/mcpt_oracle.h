@@ -122,7 +122,8 @@ void orc_material_refract(const orc_material *m, const float *I, const float *N,
 /* Philox4x32-10 (Salmon et al. 2011), for KAT tests. */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
-/* The shared transcendental functions (csrc/mcpt_fmath.h) on arrays: kind 0 sin(x), 1 cos(x), 2 atan2(x, y), 3 acos(x). */
+/* The shared transcendental functions (csrc/mcpt_fmath.h) on arrays: kind 0 sin(x), 1 cos(x), 2 atan2(x, y), 3 acos(x),
+ * 4 pow(x, y), 5 tone-map byte of x (as a float). */
 void orc_fmath(int kind, int64_t n, const float *x, const float *y, float *out);
 
 /* Tone map (Renderer.cpp:95-103): fb (W*H*3 float) -> rgba8 (W*H*4). */

@@ -181,7 +181,7 @@ def tonemap(fb):
 
 def fmath(kind, x, y=None):
     """csrc/mcpt_fmath.h on the host: kind "sin" | "cos" | "atan2" (x = first argument) | "acos"."""
-    k = {"sin": 0, "cos": 1, "atan2": 2, "acos": 3}[kind]
+    k = {"sin": 0, "cos": 1, "atan2": 2, "acos": 3, "pow": 4, "tonemap": 5}[kind]
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), dtype=np.float32)
     out = np.zeros_like(x)

@@ -61,6 +61,59 @@ def test_host_fmath_special_values(oracle):
     assert oracle.fmath("sin", [0.0])[0] == 0.0 and oracle.fmath("cos", [0.0])[0] == 1.0
 
 
+def _tone_inputs():
+    rng = np.random.default_rng(7)
+    # every float whose image 255 c^0.45 lies within a few ulps of an integer boundary is where a last-bit difference would show:
+    # take the boundary pre-images (k/255)^(1/0.45) with their neighbours, plus random radiances over the whole range
+    k = np.arange(0, 256, dtype=np.float64)
+    pre = ((k / 255.0) ** (1 / 0.45)).astype(np.float32)
+    near = np.concatenate([np.nextafter(pre, np.float32(np.inf)), np.nextafter(pre, np.float32(-np.inf)), pre])
+    for _ in range(3):
+        near = np.concatenate([near, np.nextafter(near, np.float32(np.inf)), np.nextafter(near, np.float32(-np.inf))])
+    rand = np.concatenate([rng.random(400000).astype(np.float32), (rng.random(100000) * 20).astype(np.float32),
+                           (10.0 ** rng.uniform(-12, 1, 100000)).astype(np.float32)])
+    special = np.array([0.0, -0.0, -1.0, np.nan, np.inf, 1.0, 1e-45, 1e-38, 3e38, 0.5], np.float32)
+    return np.concatenate([near.astype(np.float32), rand, special])
+
+
+def test_host_pow_and_tonemap_match_glibc(oracle):
+    """mcpt_powf against the correctly rounded x^0.45 (<= 1 ulp), and the tone-map byte against the reference's expression with
+    glibc's powf (orc_tonemap = Renderer.cpp:95-103 verbatim): identical on every tested input, including the pre-images of all
+    256 byte boundaries and their neighbours."""
+    x = _tone_inputs()
+    fin = np.isfinite(x) & (x > 0)
+    got = oracle.fmath("pow", x[fin], np.full(fin.sum(), 0.45, np.float32))
+    want = (x[fin].astype(np.float64) ** np.float64(np.float32(0.45))).astype(np.float32)
+    ul = _ulps(got, want)
+    assert ul.max() <= 1 and (ul > 0).mean() < 1e-4, (int(ul.max()), float((ul > 0).mean()))
+    ours = oracle.fmath("tonemap", x).astype(np.uint8)
+    fb = np.stack([x, x, x], axis=-1)
+    ref = oracle.tonemap(fb)[..., 0]
+    bad = ours != ref
+    assert not bad.any(), (int(bad.sum()), x[bad][:8], ours[bad][:8], ref[bad][:8])
+    assert (ours[np.isnan(x)] == 255).all() and (ours[x == np.inf] == 255).all() and (ours[x < 0] == 255).all()  # NaN clamps to the upper bound
+
+
+@pytest.mark.gpu
+def test_device_tonemap_matches_the_reference_expression(oracle, hip, pkg):
+    x = _tone_inputs()
+    n = (len(x) // 3) * 3
+    fb = x[:n].reshape(1, -1, 3)
+    hs = hip.HipScene(pkg.scenes.cornell_rc(8, 8, 1))
+    gpu = hs.tonemap(fb)
+    ref = oracle.tonemap(fb)
+    assert np.array_equal(gpu, ref), int((gpu != ref).sum())
+    # device pow == host pow bit for bit
+    fin = np.isfinite(x) & (x > 0)
+    y = np.full(fin.sum(), 0.45, np.float32)
+    a, b = oracle.fmath("pow", x[fin], y), hip.debug_fmath("pow", x[fin], y)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # a rendered frame: on-GPU tone map == the Python/NumPy mirror == the oracle's
+    sd = pkg.scenes.cornell_demo(64, 64, 4)
+    frame, _ = hip.HipScene(sd).render(spp=4, seed=1)
+    assert np.array_equal(hs.tonemap(frame)[..., :3], pkg.pngio.tonemap_u8(frame)) and np.array_equal(hs.tonemap(frame), oracle.tonemap(frame))
+
+
 @pytest.mark.gpu
 def test_device_fmath_is_bit_identical_to_host(oracle, hip):
     ang, d = _inputs()

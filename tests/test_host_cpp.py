@@ -135,3 +135,35 @@ def test_cpp_executables_render_the_oracle_image(pkg, hip, oracle, host_bins, tm
             assert pkg.pngio.psnr_u8(want, img[:, :, :3]) >= 60.0
             fb, _ = hip.HipScene(sd).render(spp=spp, seed=1)
             assert np.array_equal(img[:, :, :3], pkg.pngio.tonemap_u8(fb))
+
+
+@pytest.mark.gpu
+def test_checkpoint_and_resume(pkg, hip, host_bins, tmp_path):
+    """Pass-wise accumulation with a checkpoint file: a render that is interrupted (test hook --stop-after) and resumed by a second
+    process writes the PNG of the uninterrupted render, byte for byte; a checkpoint of another scene or size is ignored."""
+    exe = host_bins[1]
+    base = [exe, "--models", MODELS, "--width", "80", "--height", "60", "--spp", "10"]
+
+    def run(extra, out):
+        p = subprocess.run(base + ["--output", str(tmp_path / out)] + extra, cwd=str(tmp_path), capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        return p.stdout
+
+    run([], "plain.png")
+    ck = str(tmp_path / "frame.ckpt")
+    o1 = run(["--checkpoint", ck, "--checkpoint-every", "3", "--stop-after", "6"], "never_written.png")
+    assert "stopped after 6 spp" in o1 and os.path.exists(ck) and not os.path.exists(tmp_path / "never_written.png")
+    assert os.path.getsize(ck) == 40 + 80 * 60 * 3 * 4
+    o2 = run(["--checkpoint", ck, "--checkpoint-every", "3"], "resumed.png")
+    assert "resuming from" in o2 and "at 6 of 10 spp" in o2
+    assert open(tmp_path / "plain.png", "rb").read() == open(tmp_path / "resumed.png", "rb").read()
+    # a finished checkpoint: nothing left to render, the same image again
+    o3 = run(["--checkpoint", ck], "again.png")
+    assert "at 10 of 10 spp" in o3
+    assert open(tmp_path / "plain.png", "rb").read() == open(tmp_path / "again.png", "rb").read()
+    # a different frame size does not match the file: rendered from scratch
+    p = subprocess.run([exe, "--models", MODELS, "--width", "40", "--height", "30", "--spp", "4", "--checkpoint", ck, "--output", str(tmp_path / "small.png")],
+                       cwd=str(tmp_path), capture_output=True, text=True)
+    assert p.returncode == 0 and "resuming" not in p.stdout
+    fb, _ = hip.HipScene(pkg.scenes.cornell_demo(40, 30, 4)).render(spp=4, seed=1)
+    assert np.array_equal(pkg.pngio.read_png(str(tmp_path / "small.png"))[:, :, :3], pkg.pngio.tonemap_u8(fb))
