@@ -183,6 +183,31 @@ def test_render_chess_with_32_light_samples(pkg, oracle, hip, tree_env):
     assert _same_bits(fb_ref, fb_exact).all()
 
 
+def test_high_quality_scene(pkg, oracle, hip, tree_env):
+    """conf.json with model_quality "high" honoured (fixed mode; 296 274 triangles, which the shipped executable cannot reach):
+    per-path values bit-identical to the oracle with the reference's tree, frame within 60 dB with the default tree."""
+    sd = pkg.scenes.chess_high(160, 90, 4)
+    assert len(sd.triangles) == 296274
+    os_ = oracle.OracleScene(sd)
+    rng = np.random.default_rng(23)
+    n = 20000
+    pix = rng.integers(0, 160 * 90, size=n).astype(np.uint32)
+    smp = rng.integers(0, 500, size=n).astype(np.uint32)
+    ch = rng.integers(0, 3, size=n).astype(np.int32)
+    o, d = os_.camera_rays(pix, smp, seed=4)
+    ref = os_.cast_rays(o, d, pix, smp, ch, seed=4)
+    tree_env("reference", "0")
+    exact = hip.HipScene(sd).cast_rays(o, d, pix, smp, ch, seed=4)
+    assert _same_bits(ref, exact).all()
+    tree_env("sah", None)
+    fb_ref, st_ref = os_.render(spp=4, seed=1)
+    hs = hip.HipScene(sd)
+    fb_gpu, st_gpu = hs.render(spp=4, seed=1)
+    assert pkg.pngio.psnr_u8(pkg.pngio.tonemap_u8(fb_ref), pkg.pngio.tonemap_u8(fb_gpu)) >= MIN_PSNR
+    assert abs(st_gpu.ref_scene_rays - st_ref.scene_rays) <= 0.002 * st_ref.scene_rays
+    assert hs.info()["n_nodes"] == 296273 and hs.info()["quantised"] == 1
+
+
 def _with_env(sd, seed=0):
     """A synthetic 64x32 lat-long environment map (the reference's sky.png is missing from its snapshot)."""
     rng = np.random.default_rng(seed)
