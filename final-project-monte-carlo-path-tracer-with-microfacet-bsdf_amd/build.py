@@ -75,6 +75,14 @@ def build_host(verbose=False):
     return os.path.join(HERE, "host", "RayTracing")
 
 
+def build_variant(name, defines, verbose=False):
+    """An experimental build for A/B measurements (tools/ab.sh): libmcpt_hip_<name>.so with extra -D flags."""
+    return _compile(os.path.join(HERE, "libmcpt_hip_%s.so" % name), list(defines), "." + name, verbose)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":
+        print(build_variant(sys.argv[2], sys.argv[3:], verbose=False))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_check(force="--force" in sys.argv, verbose=True))

@@ -92,6 +92,12 @@ struct CameraConst {
     float orient[9];
 };
 
+// LDS traversal-stack entries per lane the traversal kernels are instantiated with for a tree of this height (a ray pushes at most
+// one child reference per inner ancestor, i.e. height - 1).  0: the tree is too deep for any instantiation.
+inline int traversal_stack_entries(int height) {
+    return height <= 16 ? 16 : (height <= 20 ? 20 : (height <= 24 ? 24 : (height <= 32 ? 32 : (height <= kMaxBvhHeight ? kMaxBvhHeight : 0))));
+}
+
 void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, uint32_t start, uint32_t mask, hipStream_t s);
 // After k_shade(cur -> next): adds this iteration's list lengths to the cumulative totals and clears the counters of
 // list `cur` (consumed; it is the next iteration's output list), in one launch.
