@@ -391,8 +391,13 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     hipStream_t s_close = ctx.side[0] ? ctx.side[0] : st, s_prim = ctx.side[1] ? ctx.side[1] : st;
 
     auto set_pass_consts = [&](int pi) {  // kernel constants of the pass occupying parity pi & 1
-        C.s_pass[pi & 1] = plan[pi].s_pass;
+        const int32_t sp = plan[pi].s_pass;
+        C.s_pass[pi & 1] = sp;
         C.sample_offset[pi & 1] = plan[pi].sample_offset;
+        int sh = -1;
+        if (sp > 0 && (sp & (sp - 1)) == 0)
+            for (sh = 0; (1 << sh) < sp; ++sh) {}
+        C.s_pass_shift[pi & 1] = sh;
     };
     // issues up to `room` new samples from the passes that may be in flight; returns how many
     auto issue = [&](Wave nx, int nxt, uint32_t room) -> uint32_t {

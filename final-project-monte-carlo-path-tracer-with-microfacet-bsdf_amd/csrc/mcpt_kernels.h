@@ -72,6 +72,7 @@ struct RenderConst {
     int32_t mode;  // 0: pid -> (pixel list, sample); 1: explicit per-path keys (mcpt_cast_rays)
     const uint32_t *pixel_list;
     int32_t s_pass[2], sample_offset[2];  // per pass parity: two passes can be in flight
+    int32_t s_pass_shift[2];              // log2(s_pass) when it is a power of two (the usual 256: a shift instead of a division), else -1
     const uint32_t *key_pixel, *key_sample;
     const int32_t *key_channel;
     int32_t max_depth;

@@ -370,14 +370,28 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Count
 // ------------------------------------------------------------------------------------------------
 // Path keys
 // ------------------------------------------------------------------------------------------------
+// s -> (position in the pixel list, sample index within the pass): s / s_pass and s % s_pass, by shift and mask when s_pass is a
+// power of two (a uniform branch; a 32-bit division by a run-time value costs ~25 vector instructions per lane)
+MCPT_DI void split_sample(const RenderConst &C, int q, uint32_t s, uint32_t &pl, uint32_t &k) {
+    const uint32_t sp = (uint32_t)(q ? C.s_pass[1] : C.s_pass[0]);
+    const int sh = q ? C.s_pass_shift[1] : C.s_pass_shift[0];
+    if (sh >= 0) {
+        pl = s >> sh;
+        k = s & (sp - 1u);
+    } else {
+        pl = s / sp;
+        k = s - pl * sp;
+    }
+}
+
 MCPT_DI void path_key(const RenderConst &C, uint32_t pid, int q, RngKey &key, int &ch) {
     if (C.mode == 0) {
-        ch = (int)(pid % 3u);
         const uint32_t s = pid / 3u;
-        const uint32_t sp = (uint32_t)(q ? C.s_pass[1] : C.s_pass[0]);
-        const uint32_t pl = s / sp;
+        ch = (int)(pid - 3u * s);
+        uint32_t pl, k;
+        split_sample(C, q, s, pl, k);
         key.pixel = C.pixel_list ? C.pixel_list[pl] : pl;
-        key.sample = (uint32_t)(q ? C.sample_offset[1] : C.sample_offset[0]) + (s % sp);
+        key.sample = (uint32_t)(q ? C.sample_offset[1] : C.sample_offset[0]) + k;
     } else {
         ch = C.key_channel[pid];
         key.pixel = C.key_pixel[pid];
@@ -438,10 +452,10 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
     TraceResult tr{DBL_MAX, -1, 0u, false};
     float *const result = q ? C.result[1] : C.result[0];
     if (valid) {
-        const uint32_t sp = (uint32_t)(q ? C.s_pass[1] : C.s_pass[0]);
-        const uint32_t pl = s / sp;
+        uint32_t pl, ks;
+        split_sample(C, q, s, pl, ks);
         const uint32_t m = C.pixel_list ? C.pixel_list[pl] : pl;
-        const uint32_t k = (uint32_t)(q ? C.sample_offset[1] : C.sample_offset[0]) + (s % sp);
+        const uint32_t k = (uint32_t)(q ? C.sample_offset[1] : C.sample_offset[0]) + ks;
         camera_ray(cam, C.seed, m, k, pos, dir);
         const Ray r = make_ray(pos, dir);
         tr = traverse<false, STK>(S, r, 0.f, stk, tid);
@@ -891,7 +905,14 @@ __global__ __launch_bounds__(kBlock, 8) void k_direct(DevScene S, RenderConst C,
     float dist = 0.f;
     uint32_t target = 0;
     if (valid) {
-        const uint32_t dj = g / n_dir, k = g % n_dir;
+        uint32_t dj, k;
+        if (n_dir == 4u) {  // the reference's fixed count (Scene.hpp:28): no division
+            dj = g >> 2;
+            k = g & 3u;
+        } else {
+            dj = g / n_dir;
+            k = g - dj * n_dir;
+        }
         const float4 v0 = Xs.vtx0[dj], v1 = Xs.vtx1[dj], v2 = Xs.vtx2[dj];
         const uint32_t j = Xs.vtx_j[dj];
         target = j * n_dir + k;
