@@ -221,6 +221,7 @@ struct mcpt_scene {
     DevBuf<LightRec> lights;
     DevBuf<LightNode> light_nodes;
     DevBuf<LightTri> light_tris;
+    DevBuf<InstRec> inst;
     DevBuf<float> env;
     DevBuf<unsigned long long> dbg;
     DevScene view{};
@@ -883,6 +884,7 @@ int mcpt_scene_create_ex(const mcpt_scene_desc *desc, int device, const mcpt_bui
     up(sc->light_nodes, hs.light_nodes);
     up(sc->light_tris, hs.light_tris);
     up(sc->env, hs.env);
+    if (!hs.instances.empty()) up(sc->inst, hs.instances);
     if (e != hipSuccess) {
         mcpt_scene_destroy(sc);
         return fail(e == hipErrorOutOfMemory ? MCPT_ERR_OOM : MCPT_ERR_HIP, std::string("scene upload: ") + hipGetErrorString(e));
@@ -942,6 +944,8 @@ int mcpt_scene_create_ex(const mcpt_scene_desc *desc, int device, const mcpt_bui
     v.lights = sc->lights.p;
     v.light_nodes = sc->light_nodes.p;
     v.light_tris = sc->light_tris.p;
+    v.inst = hs.instances.empty() ? nullptr : sc->inst.p;
+    v.n_leaf_prims = hs.n_leaf_prims;
     v.env = sc->env.p;
     for (int k = 0; k < 3; ++k) {
         v.root_min[k] = hs.root_min[k];
@@ -967,12 +971,13 @@ int mcpt_scene_create_ex(const mcpt_scene_desc *desc, int device, const mcpt_bui
     sc->info.upload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_upload).count() - gpu_build_ms;
     sc->info.builder = hs.builder;
     sc->info.quantised = sc->qnodes.p ? 1 : 0;
+    sc->info.n_instances = (int32_t)hs.instances.size();
     sc->info.n_nodes = sc->n_inner;
     sc->info.bvh_height = hs.height;
     sc->info.n_lights = v.n_lights;
     sc->info.n_prims = hs.n_triangles + hs.n_objects;
     sc->info.scene_bytes = sc->nodes.bytes() + sc->qnodes.bytes() + sc->tri_geom.bytes() + sc->tri_shade.bytes() + sc->spheres.bytes() +
-                           sc->mats.bytes() + sc->lights.bytes() + sc->light_nodes.bytes() + sc->light_tris.bytes() +
+                           sc->mats.bytes() + sc->lights.bytes() + sc->light_nodes.bytes() + sc->light_tris.bytes() + sc->inst.bytes() +
                            sc->env.bytes();
     *out = sc;
     return MCPT_OK;
@@ -1012,11 +1017,12 @@ void mcpt_scene_destroy(mcpt_scene *sc) {
     sc->shared.release();
     if (sc->fork) (void)hipEventDestroy(sc->fork);
     sc->nodes.release(); sc->qnodes.release(); sc->tri_geom.release(); sc->tri_shade.release(); sc->spheres.release(); sc->mats.release();
-    sc->lights.release(); sc->light_nodes.release(); sc->light_tris.release(); sc->env.release();
+    sc->lights.release(); sc->light_nodes.release(); sc->light_tris.release(); sc->env.release(); sc->inst.release();
     delete sc;
 }
 
-int mcpt_bvh_dump(const mcpt_scene_desc *desc, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes) {
+int mcpt_bvh_dump(const mcpt_scene_desc *desc, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes,
+                  float *inst_shift, int32_t *inst_root_first) {
     if (!desc || !info) return fail(MCPT_ERR_ARG, "mcpt_bvh_dump: null argument");
     HostScene hs;
     const char *err = "";
@@ -1030,11 +1036,18 @@ int mcpt_bvh_dump(const mcpt_scene_desc *desc, mcpt_bvh_info *info, float *boxes
     info->root = hs.root;
     info->stack_entries = hs.height;
     info->quantised = hs.qnodes.empty() ? 0 : 1;
+    info->n_instances = (int32_t)hs.instances.size();
+    info->n_leaf_prims = hs.n_leaf_prims;
     for (int k = 0; k < 3; ++k) {
         info->root_min[k] = hs.root_min[k];
         info->root_max[k] = hs.root_max[k];
         info->q_origin[k] = hs.q_origin[k];
         info->q_cell[k] = hs.q_cell[k];
+    }
+    for (size_t k = 0; k < hs.instances.size() && inst_shift && inst_root_first; ++k) {
+        for (int c = 0; c < 3; ++c) inst_shift[3 * k + c] = hs.instances[k].shift[c];
+        inst_root_first[2 * k] = hs.instances[k].root;
+        inst_root_first[2 * k + 1] = hs.instances[k].first_tri;
     }
     if (!boxes || !children) return MCPT_OK;
     for (int32_t i = 0; i < info->n_nodes; ++i) {
@@ -1060,7 +1073,8 @@ int mcpt_bvh_dump(const mcpt_scene_desc *desc, mcpt_bvh_info *info, float *boxes
     return MCPT_OK;
 }
 
-int mcpt_scene_dump_bvh(mcpt_scene *sc, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes) {
+int mcpt_scene_dump_bvh(mcpt_scene *sc, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes, float *inst_shift,
+                        int32_t *inst_root_first) {
     if (!sc || !info) return fail(MCPT_ERR_ARG, "mcpt_scene_dump_bvh: null argument");
     HIP_TRY(hipSetDevice(sc->device));
     std::memset(info, 0, sizeof *info);
@@ -1069,6 +1083,17 @@ int mcpt_scene_dump_bvh(mcpt_scene *sc, mcpt_bvh_info *info, float *boxes, int32
     info->root = v.root;
     info->stack_entries = v.height;
     info->quantised = v.qnodes ? 1 : 0;
+    info->n_instances = sc->info.n_instances;
+    info->n_leaf_prims = v.n_leaf_prims;
+    if (info->n_instances > 0 && inst_shift && inst_root_first) {
+        std::vector<InstRec> I((size_t)info->n_instances);
+        HIP_TRY(hipMemcpy(I.data(), sc->inst.p, I.size() * sizeof(InstRec), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < I.size(); ++k) {
+            for (int c = 0; c < 3; ++c) inst_shift[3 * k + c] = I[k].shift[c];
+            inst_root_first[2 * k] = I[k].root;
+            inst_root_first[2 * k + 1] = I[k].first_tri;
+        }
+    }
     for (int k = 0; k < 3; ++k) {
         info->root_min[k] = v.root_min[k];
         info->root_max[k] = v.root_max[k];

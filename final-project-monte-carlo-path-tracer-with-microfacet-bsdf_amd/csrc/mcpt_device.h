@@ -94,6 +94,8 @@ struct DevScene {
     const LightRec *lights;
     const LightNode *light_nodes;
     const LightTri *light_tris;
+    const InstRec *inst;   // instanced objects, or nullptr (plain tree); leaf index n_leaf_prims + k refers to inst[k]
+    int32_t n_leaf_prims;  // leaf indices below it are primitives
     const float *env;
     float root_min[3], root_max[3];
     float background[3];

@@ -91,6 +91,17 @@ struct alignas(16) LightRec {
 };
 static_assert(sizeof(LightRec) == 32, "LightRec must be 32 bytes");
 
+// An instanced object (csrc/mcpt_scene.cpp: instancing): the traversal NODES of its prototype's subtree are shared, shifted by
+// `shift` (box tests run with the ray origin moved by -shift); the primitive tests still read this object's own exact
+// world-space triangles, tri_geom[first_tri + local index], so hits are those of the un-instanced scene.
+struct alignas(16) InstRec {
+    float shift[3];     // object position minus prototype position
+    int32_t root;       // child reference of the prototype subtree's root (inner node index)
+    int32_t first_tri;  // this object's first triangle (global primitive id of local index 0)
+    int32_t pad[3];
+};
+static_assert(sizeof(InstRec) == 32, "InstRec must be 32 bytes");
+
 // Area tree of a light mesh, for BVHAccel::getSample (BVH.cpp:118-129).
 struct alignas(16) LightNode {
     float left_area;   // node->left->area
@@ -129,6 +140,8 @@ struct HostScene {
     int32_t height = 0;
     int32_t builder = 0;                  // 0 host binned SAH, 1 host reference topology, 2 GPU LBVH (mcpt_scene_info::builder)
     std::vector<int32_t> sphere_objects;  // object index of every sphere object (the GPU builder's primitive list)
+    std::vector<InstRec> instances;       // instanced objects (empty: plain single-level tree); leaf reference ~(n_leaf_prims + k)
+    int32_t n_leaf_prims = 0;             // n_triangles + n_objects: leaf indices below it are primitives, from it on instances
     float background[3];
     int32_t env_w = 0, env_h = 0;
     std::vector<float> env;
@@ -141,6 +154,7 @@ struct HostScene {
 struct BuildChoice {
     int32_t builder = MCPT_BUILD_SAH;  // MCPT_BUILD_SAH | MCPT_BUILD_REFERENCE | MCPT_BUILD_GPU_LBVH
     int32_t quantise = -1;             // -1 automatic, 0 never, 1 always
+    int32_t instancing = -1;           // -1 automatic (large scenes with repeated meshes), 0 never, 1 whenever a mesh repeats
 };
 BuildChoice resolve_build_choice(const mcpt_build_options *opt);
 

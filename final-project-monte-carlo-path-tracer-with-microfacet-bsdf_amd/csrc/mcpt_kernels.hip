@@ -144,12 +144,21 @@ struct TraceState {
 // 4: 4515, 8: 4540, 12: 4540, 16: 4525; testing the second leaf in the same round instead of parking it: 4430.  The serialised
 // k_trace_closest went from 82.5 to 72 ms per 2 x 256 spp.  Same tests, same results: the order of primitive tests does not
 // matter (ties go to the larger primitive id), and the pruning margins are unchanged.
-constexpr int32_t kNoWork = (int32_t)0x80000000;  // neither an inner node (>= 0) nor a leaf (~primitive, primitive < 2^31 - 1)
+//
+// INST (scenes with instanced objects, csrc/mcpt_scene.cpp): a leaf index >= n_leaf_prims is an instance.  Entering it moves the
+// origin used by the BOX tests by -shift, pushes an exit marker and continues in the prototype's shared subtree, whose leaves hold
+// local triangle indices; primitive tests always use the world ray and the object's own world-space triangle
+// (first_tri + local index), so hits are exactly those of the un-instanced tree.  Popping the marker restores the origin.
+constexpr int32_t kNoWork = (int32_t)0x80000000;   // neither an inner node (>= 0) nor a leaf (~index, index < 2^31 - 2)
+constexpr int32_t kInstExit = (int32_t)0x80000001; // stack marker: the subtree of the current instance is exhausted
 constexpr int kLeafVote = 12;
-template <int MODE, int STK, bool FAST, bool QUANT>
+template <int MODE, int STK, bool FAST, bool QUANT, bool INST>
 MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, TraceState &st) {
     QRay qr;
     if (QUANT) qr = make_qray(S, r);
+    Ray rb = r;               // the ray of the box tests (origin shifted inside an instance)
+    int32_t prim_base = 0;    // first triangle of the current instance (0 at the top level: leaf indices are primitive ids)
+    const uint32_t n_leaf_prims = INST ? (uint32_t)S.n_leaf_prims : 0x7ffffffeu;
     const float margin = dist * 1e-4f + 1e-2f;
     float lim = (MODE == kClosest) ? INFINITY : (dist + margin);
     const float lo = dist - margin;
@@ -158,7 +167,7 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
     if (!box_hit<FAST>(S.root_min, S.root_max, r, tm, tx)) return;
     int sp = 0;
     int32_t leaf = kNoWork;
-    if (cur < 0) {  // the root is a leaf (a scene of one primitive)
+    if (cur < 0 && (uint32_t)(~cur) < n_leaf_prims) {  // the root is a leaf (a scene of one primitive)
         leaf = cur;
         cur = kNoWork;
     }
@@ -168,6 +177,22 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
 #ifdef MCPT_TRAVERSAL_STATS
             st.iters++;
 #endif
+            if (INST) {
+                if (cur == kInstExit) {  // back to the top level
+                    rb.o = r.o;
+                    prim_base = 0;
+                    if (QUANT) qr.b = make_qray(S, r).b;
+                    cur = (sp == 0) ? kNoWork : stk[--sp][tid];
+                }
+                if (cur > kInstExit && cur < 0 && (uint32_t)(~cur) >= n_leaf_prims) {  // an instance: enter its prototype's subtree
+                    const InstRec I = S.inst[(uint32_t)(~cur) - n_leaf_prims];
+                    rb.o = mk3(r.o.x - I.shift[0], r.o.y - I.shift[1], r.o.z - I.shift[2]);
+                    prim_base = I.first_tri;
+                    if (QUANT) qr.b = make_qray(S, rb).b;
+                    if (sp < STK) stk[sp++][tid] = kInstExit;
+                    cur = I.root;
+                }
+            }
             if (cur >= 0) {
 #ifdef MCPT_TRAVERSAL_STATS
                 st.nv++;
@@ -181,8 +206,8 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
                     const uint4 a = np[0], b = np[1];
                     left = (int32_t)b.z;
                     right = (int32_t)b.w;
-                    hl = qbox_hit<FAST>(S, r, qr, a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16, a.z & 0xffffu, a.z >> 16, tl, txl);
-                    hr = qbox_hit<FAST>(S, r, qr, a.w & 0xffffu, a.w >> 16, b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16, tr, txr);
+                    hl = qbox_hit<FAST>(S, rb, qr, a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16, a.z & 0xffffu, a.z >> 16, tl, txl);
+                    hr = qbox_hit<FAST>(S, rb, qr, a.w & 0xffffu, a.w >> 16, b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16, tr, txr);
                 } else {
                     const float4 *np = reinterpret_cast<const float4 *>(S.nodes + cur);
                     const float4 a = np[0], b = np[1], c = np[2], e = np[3];
@@ -190,8 +215,8 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
                     const float rmin[3] = {b.z, b.w, c.x}, rmax[3] = {c.y, c.z, c.w};
                     left = __float_as_int(e.x);
                     right = __float_as_int(e.y);
-                    hl = box_hit<FAST>(lmin, lmax, r, tl, txl);
-                    hr = box_hit<FAST>(rmin, rmax, r, tr, txr);
+                    hl = box_hit<FAST>(lmin, lmax, rb, tl, txl);
+                    hr = box_hit<FAST>(rmin, rmax, rb, tr, txr);
                 }
                 hl = hl && !(tl > lim);
                 hr = hr && !(tr > lim);
@@ -211,12 +236,14 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
                 } else {
                     cur = (sp == 0) ? kNoWork : stk[--sp][tid];
                 }
-                if (cur < 0 && cur != kNoWork && leaf == kNoWork) {  // first leaf of the round: park it and keep traversing
-                    leaf = cur;
+                if (cur < 0 && (uint32_t)(~cur) < n_leaf_prims && leaf == kNoWork) {  // first leaf of the round: park it and keep traversing
+                    leaf = ~(prim_base + ~cur);  // (a global primitive id from here on)
                     cur = (sp == 0) ? kNoWork : stk[--sp][tid];
                 }
             }
-            if (__popcll(__ballot(leaf == kNoWork && cur >= 0)) <= kLeafVote) break;
+            // a lane can still make progress on nodes if it holds an inner node (or, INST, an instance / exit marker)
+            const bool workable = INST ? (cur >= 0 || (cur > kNoWork && (uint32_t)(~cur) >= n_leaf_prims)) : (cur >= 0);
+            if (__popcll(__ballot(leaf == kNoWork && workable)) <= kLeafVote) break;
         }
         // ---- phase 2: the parked leaf
         if (leaf != kNoWork) {
@@ -254,8 +281,8 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
                 }
             }
             leaf = kNoWork;
-            if (cur < 0 && cur != kNoWork) {  // a second leaf was waiting: park it for the next round
-                leaf = cur;
+            if (cur < 0 && (uint32_t)(~cur) < n_leaf_prims) {  // a second leaf was waiting: park it for the next round
+                leaf = ~(prim_base + ~cur);
                 cur = (sp == 0) ? kNoWork : stk[--sp][tid];
             }
         }
@@ -287,10 +314,15 @@ MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_
 #ifdef MCPT_TRAVERSAL_STATS
     st.nv = st.nt = st.iters = 0;
 #endif
-#define TL(MODE, FAST)                                                              \
-    do {                                                                            \
-        if (S.qnodes) traverse_loop<MODE, STK, FAST, true>(S, r, dist, stk, tid, st); \
-        else traverse_loop<MODE, STK, FAST, false>(S, r, dist, stk, tid, st);       \
+#define TL(MODE, FAST)                                                                           \
+    do {                                                                                         \
+        if (S.inst) {                                                                            \
+            if (S.qnodes) traverse_loop<MODE, STK, FAST, true, true>(S, r, dist, stk, tid, st);  \
+            else traverse_loop<MODE, STK, FAST, false, true>(S, r, dist, stk, tid, st);          \
+        } else {                                                                                 \
+            if (S.qnodes) traverse_loop<MODE, STK, FAST, true, false>(S, r, dist, stk, tid, st); \
+            else traverse_loop<MODE, STK, FAST, false, false>(S, r, dist, stk, tid, st);         \
+        }                                                                                        \
     } while (0)
     // Wave-uniform choice of the slab-test flavour: the exact NaN-faithful chain only when some lane of the wave
     // has a non-finite reciprocal (a zero direction component); otherwise the bit-identical max3/min3 form.

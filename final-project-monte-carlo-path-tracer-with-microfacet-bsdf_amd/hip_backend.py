@@ -54,7 +54,7 @@ class Stats(C.Structure):
 
 
 class BuildOptions(C.Structure):
-    _fields_ = [("builder", C.c_int32), ("quantise", C.c_int32), ("reserved", C.c_int32 * 6)]
+    _fields_ = [("builder", C.c_int32), ("quantise", C.c_int32), ("instancing", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 BUILDERS = {"default": 0, "sah": 1, "reference": 2, "lbvh": 3}  # MCPT_BUILD_*
@@ -63,7 +63,7 @@ BUILDERS = {"default": 0, "sah": 1, "reference": 2, "lbvh": 3}  # MCPT_BUILD_*
 class SceneInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("bvh_height", C.c_int32), ("n_lights", C.c_int32), ("n_prims", C.c_int32),
                 ("scene_bytes", C.c_uint64), ("build_ms", C.c_double), ("upload_ms", C.c_double), ("builder", C.c_int32),
-                ("quantised", C.c_int32)]
+                ("quantised", C.c_int32), ("n_instances", C.c_int32), ("pad", C.c_int32)]
 
 
 _libs = {}
@@ -83,7 +83,7 @@ def lib(path=None):
         L.mcpt_scene_create_ex.restype = C.c_int
         L.mcpt_scene_create_ex.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.mcpt_scene_dump_bvh.restype = C.c_int
-        L.mcpt_scene_dump_bvh.argtypes = [C.c_void_p, C.POINTER(BvhInfo), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcpt_scene_dump_bvh.argtypes = [C.c_void_p, C.POINTER(BvhInfo), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcpt_tonemap.restype = C.c_int
         L.mcpt_tonemap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.mcpt_tonemap_device.restype = C.c_int
@@ -93,7 +93,7 @@ def lib(path=None):
         L.mcpt_scene_get_info.restype = C.c_int
         L.mcpt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
         L.mcpt_bvh_dump.restype = C.c_int
-        L.mcpt_bvh_dump.argtypes = [C.POINTER(SceneDesc), C.POINTER(BvhInfo), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcpt_bvh_dump.argtypes = [C.POINTER(SceneDesc), C.POINTER(BvhInfo), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcpt_render.restype = C.c_int
         L.mcpt_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]
         L.mcpt_render_device.restype = C.c_int
@@ -133,7 +133,8 @@ def _ptr(a):
 
 class BvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("root", C.c_int32), ("stack_entries", C.c_int32), ("quantised", C.c_int32),
-                ("root_min", C.c_float * 3), ("root_max", C.c_float * 3), ("q_origin", C.c_float * 3), ("q_cell", C.c_float * 3)]
+                ("root_min", C.c_float * 3), ("root_max", C.c_float * 3), ("q_origin", C.c_float * 3), ("q_cell", C.c_float * 3),
+                ("n_instances", C.c_int32), ("n_leaf_prims", C.c_int32)]
 
 
 def _make_desc(sd, keep):
@@ -157,20 +158,26 @@ def bvh_dump(sd):
     keep = []
     d = _make_desc(sd, keep)
     info = BvhInfo()
-    _check(lib().mcpt_bvh_dump(C.byref(d), C.byref(info), None, None, None))
+    _check(lib().mcpt_bvh_dump(C.byref(d), C.byref(info), None, None, None, None, None))
     n = info.n_nodes
     boxes = np.zeros((n, 12), np.float32)
     children = np.zeros((n, 2), np.int32)
     qboxes = np.zeros((n, 12), np.uint16)
-    _check(lib().mcpt_bvh_dump(C.byref(d), C.byref(info), _ptr(boxes), _ptr(children), _ptr(qboxes)))
+    shift, root_first = np.zeros((info.n_instances, 3), np.float32), np.zeros((info.n_instances, 2), np.int32)
+    _check(lib().mcpt_bvh_dump(C.byref(d), C.byref(info), _ptr(boxes), _ptr(children), _ptr(qboxes), _ptr(shift), _ptr(root_first)))
+    return _bvh_info_dict(info, shift, root_first), boxes, children, (qboxes if info.quantised else None)
+
+
+def _bvh_info_dict(info, shift, root_first):
     out = {k: (list(getattr(info, k)) if k in ("root_min", "root_max", "q_origin", "q_cell") else getattr(info, k)) for k, _ in info._fields_}
-    return out, boxes, children, (qboxes if info.quantised else None)
+    out["inst_shift"], out["inst_root_first"] = shift, root_first
+    return out
 
 
 class HipScene:
     """A scene resident in the HBM of one GPU (mcpt_scene_create)."""
 
-    def __init__(self, sd, device=-1, library=None, builder=None, quantise=-1):
+    def __init__(self, sd, device=-1, library=None, builder=None, quantise=-1, instancing=None):
         """library: path of an alternative build of the same ABI (the checking build); None = the product library.
         builder: None (mcpt_scene_create: environment / default) or "sah" | "reference" | "lbvh" (mcpt_scene_create_ex)."""
         self.sd = sd
@@ -179,22 +186,24 @@ class HipScene:
         d = _make_desc(sd, self._keep)
         h = C.c_void_p()
         self.h = None
-        if builder is None and quantise == -1:
+        if builder is None and quantise == -1 and instancing is None:
             _check(self.L.mcpt_scene_create(C.byref(d), int(device), C.byref(h)), L=self.L)
         else:
-            opt = BuildOptions(builder=BUILDERS[builder or "default"], quantise=int(quantise))
+            # instancing: None automatic, False never, True whenever a mesh repeats (MCPT_INSTANCING_*)
+            opt = BuildOptions(builder=BUILDERS[builder or "default"], quantise=int(quantise),
+                               instancing=0 if instancing is None else (2 if instancing else 1))
             _check(self.L.mcpt_scene_create_ex(C.byref(d), int(device), C.byref(opt), C.byref(h)), L=self.L)
         self.h = h
 
     def dump_bvh(self):
         """The traversal tree as it sits in HBM: (info dict, boxes[n,12], children[n,2], qboxes[n,12] or None)."""
         info = BvhInfo()
-        _check(self.L.mcpt_scene_dump_bvh(self.h, C.byref(info), None, None, None), L=self.L)
+        _check(self.L.mcpt_scene_dump_bvh(self.h, C.byref(info), None, None, None, None, None), L=self.L)
         n = info.n_nodes
         boxes, children, qboxes = np.zeros((n, 12), np.float32), np.zeros((n, 2), np.int32), np.zeros((n, 12), np.uint16)
-        _check(self.L.mcpt_scene_dump_bvh(self.h, C.byref(info), _ptr(boxes), _ptr(children), _ptr(qboxes)), L=self.L)
-        out = {k: (list(getattr(info, k)) if k in ("root_min", "root_max", "q_origin", "q_cell") else getattr(info, k)) for k, _ in info._fields_}
-        return out, boxes, children, (qboxes if info.quantised else None)
+        shift, root_first = np.zeros((info.n_instances, 3), np.float32), np.zeros((info.n_instances, 2), np.int32)
+        _check(self.L.mcpt_scene_dump_bvh(self.h, C.byref(info), _ptr(boxes), _ptr(children), _ptr(qboxes), _ptr(shift), _ptr(root_first)), L=self.L)
+        return _bvh_info_dict(info, shift, root_first), boxes, children, (qboxes if info.quantised else None)
 
     def close(self):
         if getattr(self, "h", None):

@@ -139,8 +139,15 @@ enum { MCPT_BUILD_DEFAULT = 0, MCPT_BUILD_SAH = 1, MCPT_BUILD_REFERENCE = 2, MCP
 typedef struct {
     int32_t builder;  /* MCPT_BUILD_* */
     int32_t quantise; /* -1 automatic, 0 float nodes (64 B), 1 quantised nodes (32 B) */
-    int32_t reserved[6];
+    /* Node instancing (host SAH builder only).  Meshes that are translated copies of one another -- the 14 soldiers of main.cpp:248-271
+     * are one OBJ file at 14 positions -- share ONE subtree of traversal nodes, entered with the ray origin shifted; every primitive test
+     * still uses the object's own world-space triangle as the reference stores it (Triangle.hpp:99-124), so hits are unchanged.  It is
+     * a memory feature (the 296 k-triangle scene: 56.9 -> 31.3 MB in HBM), measured slower than the plain tree on MI355X, so the default
+     * (MCPT_INSTANCING_AUTO) leaves it off. */
+    int32_t instancing; /* MCPT_INSTANCING_AUTO (0) | MCPT_INSTANCING_OFF (1) | MCPT_INSTANCING_ON (2); env override MCPT_INSTANCING = 0 | 1 */
+    int32_t reserved[5];
 } mcpt_build_options;
+enum { MCPT_INSTANCING_AUTO = 0, MCPT_INSTANCING_OFF = 1, MCPT_INSTANCING_ON = 2 };
 int mcpt_scene_create_ex(const mcpt_scene_desc *desc, int device, const mcpt_build_options *options, mcpt_scene **out);
 
 /* Replaces the pixel/spp loop of Renderer::Render (Renderer.cpp:21-91): fb_host = W*H*3 floats,
@@ -197,6 +204,8 @@ typedef struct {
     double upload_ms; /* host -> HBM copies */
     int32_t builder;  /* 0 host binned SAH, 1 host reference topology (median split), 2 GPU LBVH */
     int32_t quantised;/* 1: 32-byte nodes with 16-bit boxes are traversed */
+    int32_t n_instances; /* objects whose traversal nodes are shared with a prototype (0: plain tree) */
+    int32_t pad;
 } mcpt_scene_info;
 int mcpt_scene_get_info(const mcpt_scene *scene, mcpt_scene_info *info);
 
@@ -206,15 +215,21 @@ int mcpt_scene_get_info(const mcpt_scene *scene, mcpt_scene_info *info);
  *   boxes[n][12]    float  {lmin.xyz, lmax.xyz, rmin.xyz, rmax.xyz} of the two children
  *   children[n][2]  int32  child >= 0: inner node index; < 0: leaf, primitive id = ~child
  *   qboxes[n][12]   uint16 the same boxes on the 16-bit grid (only written when info->quantised)
- * Primitive ids: triangle index, or n_triangles + object index for a sphere. */
+ * Primitive ids: triangle index, or n_triangles + object index for a sphere.
+ * With instancing, a leaf index (~child) >= n_leaf_prims is instance k = index - n_leaf_prims: the subtree at inst_root_first[k][0],
+ * whose boxes are in the prototype's position (this object's position = prototype + inst_shift[k]) and whose leaves hold LOCAL
+ * triangle indices (global id = inst_root_first[k][1] + local).  inst_* may be NULL. */
 typedef struct {
     int32_t n_nodes, root, stack_entries, quantised;
     float root_min[3], root_max[3];
     float q_origin[3], q_cell[3]; /* grid coordinate q <-> q_origin + q * q_cell */
+    int32_t n_instances, n_leaf_prims;
 } mcpt_bvh_info;
-int mcpt_bvh_dump(const mcpt_scene_desc *desc, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes);
+int mcpt_bvh_dump(const mcpt_scene_desc *desc, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes,
+                  float *inst_shift, int32_t *inst_root_first);
 /* The same arrays downloaded from a live scene (whatever built its tree, the GPU builder included). */
-int mcpt_scene_dump_bvh(mcpt_scene *scene, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes);
+int mcpt_scene_dump_bvh(mcpt_scene *scene, mcpt_bvh_info *info, float *boxes, int32_t *children, uint16_t *qboxes,
+                        float *inst_shift, int32_t *inst_root_first);
 
 /* Diagnostic: evaluates the path's transcendental functions (csrc/mcpt_fmath.h: the library's own plain-IEEE sin / cos /
  * atan2 / acos, used where the reference calls libm at Material.hpp:117-118, Renderer.cpp:59-60, Sphere.hpp:66-67,

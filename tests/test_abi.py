@@ -29,7 +29,7 @@ def test_struct_sizes_match_header(hip, pkg):
     assert C.sizeof(hip.SceneDesc) == 64   # 5 int32 + 3 float + 4 pointers
     assert C.sizeof(hip.Params) == 14 * 4
     assert C.sizeof(hip.Stats) == 9 * 8 + 6 * 8 + 5 * 8 + 3 * 8
-    assert C.sizeof(hip.SceneInfo) == 48
+    assert C.sizeof(hip.SceneInfo) == 56
 
 
 def test_no_cpu_fallback_without_gpu(hip, pkg):

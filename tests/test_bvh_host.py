@@ -25,15 +25,28 @@ def check_tree(sd, info, boxes, children, qboxes):
     seen = np.zeros(len(pmn), np.int32)
     eps = 1e-5
 
-    def subtree(ref):  # -> (mn, mx, height) of everything below a child reference
+    n_leaf = info.get("n_leaf_prims") or (len(pmn) + 1)
+    shifts, root_first = info.get("inst_shift"), info.get("inst_root_first")
+
+    def subtree(ref, shift=None, base=0):  # -> (mn, mx, height) of everything below a child reference
+        if ref < 0 and ~ref >= n_leaf:
+            # an instance: its prototype's subtree holds boxes in the prototype's position and local triangle indices; every box
+            # below must contain THIS object's triangle moved back by the shift (checked in float64), and the instance's own
+            # leaf box (world position) must contain the object.  One extra stack entry for the exit marker.
+            k = ~ref - n_leaf
+            assert shift is None, "nested instances"
+            cmn, cmx, ch = subtree(int(root_first[k][0]), shift=shifts[k].astype(np.float64), base=int(root_first[k][1]))
+            return cmn + shifts[k], cmx + shifts[k], ch + 1
         if ref < 0:
-            p = ~ref
+            p = base + ~ref
             seen[p] += 1
+            if shift is not None:
+                return pmn[p].astype(np.float64) - shift, pmx[p].astype(np.float64) - shift, 0
             return pmn[p], pmx[p], 0
         b = boxes[ref]
         out_mn, out_mx, h = None, None, 0
         for side, cref in enumerate(children[ref]):
-            cmn, cmx, ch = subtree(int(cref))
+            cmn, cmx, ch = subtree(int(cref), shift, base)
             box_mn, box_mx = b[6 * side:6 * side + 3], b[6 * side + 3:6 * side + 6]
             assert (box_mn <= cmn + eps).all() and (box_mx >= cmx - eps).all(), (ref, side)
             out_mn = box_mn if out_mn is None else np.minimum(out_mn, box_mn)
@@ -99,3 +112,27 @@ def test_random_soup_and_single_primitive(pkg, hip):
     one.objects["n_tri"] = 1
     info, boxes, children, qboxes = hip.bvh_dump(one)
     assert info["n_nodes"] == 0 and info["root"] == ~0
+
+
+def test_instanced_soldiers_share_one_subtree(pkg, hip, monkeypatch):
+    """Node instancing (host SAH builder): the 14 soldiers (one OBJ at 14 translations, main.cpp:248-271) become 14 instance leaves over ONE
+    shared subtree; every other invariant holds for each instance with its own triangles.  Opt-in (measured slower than the plain
+    tree: a memory feature)."""
+    sd = pkg.scenes.chess_scene(width=64, height=64, spp=1)
+    plain, *_ = hip.bvh_dump(sd)
+    assert plain["n_instances"] == 0 and plain["n_nodes"] == 38457  # default: off
+    monkeypatch.setenv("MCPT_INSTANCING", "1")
+    info, boxes, children, qboxes = hip.bvh_dump(sd)
+    assert info["n_instances"] == 14 and info["n_leaf_prims"] == len(sd.triangles) + len(sd.objects)
+    assert info["n_nodes"] == (2560 - 1) + (14 + 2312 + 302 + 2 + 2 - 1)  # one soldier subtree + the tree over everything else
+    assert len(set(info["inst_root_first"][:, 0].tolist())) == 1 and sorted(info["inst_root_first"][:, 1].tolist()) == [2560 * k for k in range(14)]
+    h = check_tree(sd, info, boxes, children, qboxes)
+    assert h <= info["stack_entries"] <= 32
+    monkeypatch.setenv("MCPT_INSTANCING", "0")
+    assert hip.bvh_dump(sd)[0]["n_instances"] == 0
+    high = pkg.scenes.chess_high(64, 64, 1)
+    assert hip.bvh_dump(high)[0]["n_instances"] == 0
+    monkeypatch.setenv("MCPT_INSTANCING", "1")
+    info, boxes, children, qboxes = hip.bvh_dump(high)
+    assert info["n_instances"] == 14 and info["n_nodes"] == (20480 - 1) + (14 + 9248 + 302 + 2 + 2 - 1)
+    check_tree(high, info, boxes, children, qboxes)
