@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -197,48 +198,19 @@ inline bool inflate(const std::vector<uint8_t> &z, std::vector<uint8_t> &out) {
     return true;
 }
 
-// Decodes an 8-bit gray / gray+alpha / RGB / RGBA PNG into RGBA8.  Returns an error text or "".
-inline std::string decode_rgba(const std::string &path, std::vector<uint8_t> &rgba, unsigned &w, unsigned &h) {
-    FILE *f = std::fopen(path.c_str(), "rb");
-    if (!f) return "failed to open file for reading";
-    std::vector<uint8_t> data;
-    uint8_t buf[65536];
-    size_t n;
-    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + n);
-    std::fclose(f);
-    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
-    if (data.size() < 8 || std::memcmp(data.data(), sig, 8) != 0) return "incorrect PNG signature";
-    std::vector<uint8_t> z;
-    int depth = 0, ctype = 0, interlace = 0;
-    size_t pos = 8;
-    while (pos + 12 <= data.size()) {
-        const uint32_t len = (data[pos] << 24) | (data[pos + 1] << 16) | (data[pos + 2] << 8) | data[pos + 3];
-        const std::string tag((const char *)&data[pos + 4], 4);
-        if (pos + 12 + len > data.size()) return "truncated chunk";
-        const uint8_t *body = &data[pos + 8];
-        if (tag == "IHDR" && len >= 13) {
-            w = (body[0] << 24) | (body[1] << 16) | (body[2] << 8) | body[3];
-            h = (body[4] << 24) | (body[5] << 16) | (body[6] << 8) | body[7];
-            depth = body[8]; ctype = body[9]; interlace = body[12];
-        } else if (tag == "IDAT") {
-            z.insert(z.end(), body, body + len);
-        } else if (tag == "IEND") {
-            break;
-        }
-        pos += 12 + len;
-    }
-    if (depth != 8 || interlace != 0 || !(ctype == 0 || ctype == 2 || ctype == 4 || ctype == 6)) return "unsupported PNG layout";
-    const int c = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : 4;
-    std::vector<uint8_t> raw;
-    if (!inflate(z, raw) || raw.size() < (size_t)h * (1 + (size_t)w * c)) return "corrupt zlib stream";
-    const size_t stride = (size_t)w * c;
-    std::vector<uint8_t> img((size_t)h * stride), prev(stride, 0);
+// Undoes the scanline filters of one (sub-)image of `h` rows of `stride` bytes (bpp = bytes per complete pixel, at least 1).
+inline bool unfilter(const uint8_t *raw, size_t raw_size, unsigned h, size_t stride, int bpp, std::vector<uint8_t> &img) {
+    if (raw_size < (size_t)h * (stride + 1)) return false;
+    img.assign((size_t)h * stride, 0);
+    std::vector<uint8_t> zero(stride, 0);
     for (unsigned y = 0; y < h; ++y) {
         const uint8_t ft = raw[y * (stride + 1)];
         const uint8_t *line = &raw[y * (stride + 1) + 1];
         uint8_t *cur = &img[y * stride];
+        const uint8_t *prev = y ? &img[(y - 1) * stride] : zero.data();
+        if (ft > 4) return false;
         for (size_t x = 0; x < stride; ++x) {
-            const int a = x >= (size_t)c ? cur[x - c] : 0, b = prev[x], cc = x >= (size_t)c ? prev[x - c] : 0;
+            const int a = x >= (size_t)bpp ? cur[x - bpp] : 0, b = prev[x], cc = x >= (size_t)bpp ? prev[x - bpp] : 0;
             int pred = 0;
             if (ft == 1) pred = a;
             else if (ft == 2) pred = b;
@@ -249,16 +221,118 @@ inline std::string decode_rgba(const std::string &path, std::vector<uint8_t> &rg
             }
             cur[x] = (uint8_t)(line[x] + pred);
         }
-        std::memcpy(prev.data(), cur, stride);
     }
-    rgba.resize((size_t)w * h * 4);
-    for (size_t i = 0; i < (size_t)w * h; ++i) {
-        const uint8_t *p = &img[i * c];
-        uint8_t *o = &rgba[i * 4];
-        if (c == 1) { o[0] = o[1] = o[2] = p[0]; o[3] = 255; }
-        else if (c == 2) { o[0] = o[1] = o[2] = p[0]; o[3] = p[1]; }
-        else if (c == 3) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = 255; }
-        else { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3]; }
+    return true;
+}
+
+// Decodes any PNG into RGBA8, converting as the reference's lodepng::decode(.., LCT_RGBA, 8) does (Scene.hpp:41): grey and palette
+// images at 1/2/4/8 bits (grey scaled by 255 / max, palette through PLTE with tRNS alpha), 16-bit samples reduced to their high
+// byte, colour keys (tRNS) giving alpha 0, Adam7-interlaced files.  Returns an error text or "".
+inline std::string decode_rgba(const std::string &path, std::vector<uint8_t> &rgba, unsigned &w, unsigned &h) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return "failed to open file for reading";
+    std::vector<uint8_t> data;
+    uint8_t buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + n);
+    std::fclose(f);
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (data.size() < 8 || std::memcmp(data.data(), sig, 8) != 0) return "incorrect PNG signature";
+    std::vector<uint8_t> z, plte, trns;
+    int depth = 0, ctype = -1, interlace = 0;
+    w = h = 0;
+    size_t pos = 8;
+    while (pos + 12 <= data.size()) {
+        const uint32_t len = ((uint32_t)data[pos] << 24) | (data[pos + 1] << 16) | (data[pos + 2] << 8) | data[pos + 3];
+        const std::string tag((const char *)&data[pos + 4], 4);
+        if (len > data.size() || pos + 12 + len > data.size()) return "truncated chunk";
+        const uint8_t *body = &data[pos + 8];
+        if (tag == "IHDR" && len >= 13) {
+            w = ((uint32_t)body[0] << 24) | (body[1] << 16) | (body[2] << 8) | body[3];
+            h = ((uint32_t)body[4] << 24) | (body[5] << 16) | (body[6] << 8) | body[7];
+            depth = body[8]; ctype = body[9]; interlace = body[12];
+        } else if (tag == "PLTE") {
+            plte.assign(body, body + len);
+        } else if (tag == "tRNS") {
+            trns.assign(body, body + len);
+        } else if (tag == "IDAT") {
+            z.insert(z.end(), body, body + len);
+        } else if (tag == "IEND") {
+            break;
+        }
+        pos += 12 + len;
+    }
+    const int c = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    const bool depth_ok = (ctype == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
+                          (ctype == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
+                          ((ctype == 2 || ctype == 4 || ctype == 6) && (depth == 8 || depth == 16));
+    if (c == 0 || !depth_ok || interlace > 1) return "unsupported PNG layout";
+    if (w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) return "image dimensions out of range";  // 268 M pixels: 1 GiB of RGBA
+    if (ctype == 3 && plte.size() < 3) return "palette image without PLTE";
+    try {
+        std::vector<uint8_t> raw;
+        if (!inflate(z, raw)) return "corrupt zlib stream";
+        const int bits = c * depth;              // bits per pixel
+        const int bpp = std::max(1, bits / 8);   // filter distance
+        rgba.assign((size_t)w * h * 4, 255);
+        // writes pixel (x, y) from sample position `i` of an unfiltered row
+        auto put = [&](const uint8_t *row, size_t i, unsigned x, unsigned y) {
+            uint8_t *o = &rgba[((size_t)y * w + x) * 4];
+            auto sample16 = [&](size_t k) { return (unsigned)(row[2 * k] << 8 | row[2 * k + 1]); };
+            if (ctype == 0 || ctype == 3) {
+                unsigned v;
+                if (depth == 16) v = sample16(i);
+                else if (depth == 8) v = row[i];
+                else v = (row[(i * depth) >> 3] >> (8 - depth - ((i * depth) & 7))) & ((1u << depth) - 1u);
+                if (ctype == 3) {
+                    if ((size_t)v * 3 + 2 < plte.size()) { o[0] = plte[3 * v]; o[1] = plte[3 * v + 1]; o[2] = plte[3 * v + 2]; }
+                    else { o[0] = o[1] = o[2] = 0; }
+                    o[3] = v < trns.size() ? trns[v] : 255;
+                } else {
+                    const bool keyed = trns.size() >= 2 && v == (unsigned)(trns[0] << 8 | trns[1]);
+                    o[0] = o[1] = o[2] = depth == 16 ? (uint8_t)(v >> 8) : depth == 8 ? (uint8_t)v : (uint8_t)((v * 255u) / ((1u << depth) - 1u));
+                    o[3] = keyed ? 0 : 255;
+                }
+            } else if (depth == 8) {
+                const uint8_t *p = &row[i * c];
+                if (c == 2) { o[0] = o[1] = o[2] = p[0]; o[3] = p[1]; }
+                else {
+                    o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+                    o[3] = c == 4 ? p[3] : ((trns.size() >= 6 && p[0] == trns[1] && p[1] == trns[3] && p[2] == trns[5] && !trns[0] && !trns[2] && !trns[4]) ? 0 : 255);
+                }
+            } else {  // 16-bit: the high byte (lodepng's reduction)
+                const size_t k = i * c;
+                if (c == 2) { o[0] = o[1] = o[2] = row[2 * k]; o[3] = row[2 * k + 2]; }
+                else {
+                    o[0] = row[2 * k]; o[1] = row[2 * k + 2]; o[2] = row[2 * k + 4];
+                    const bool keyed = c == 3 && trns.size() >= 6 && sample16(k) == (unsigned)(trns[0] << 8 | trns[1]) &&
+                                       sample16(k + 1) == (unsigned)(trns[2] << 8 | trns[3]) && sample16(k + 2) == (unsigned)(trns[4] << 8 | trns[5]);
+                    o[3] = c == 4 ? row[2 * k + 6] : (keyed ? 0 : 255);
+                }
+            }
+        };
+        std::vector<uint8_t> img;
+        if (!interlace) {
+            const size_t stride = ((size_t)w * bits + 7) / 8;
+            if (!unfilter(raw.data(), raw.size(), h, stride, bpp, img)) return "corrupt image data";
+            for (unsigned y = 0; y < h; ++y)
+                for (unsigned x = 0; x < w; ++x) put(&img[y * stride], x, x, y);
+        } else {  // Adam7: seven reduced images, one after the other
+            static const unsigned x0[7] = {0, 4, 0, 2, 0, 1, 0}, y0[7] = {0, 0, 4, 0, 2, 0, 1}, dx[7] = {8, 8, 4, 4, 2, 2, 1}, dy[7] = {8, 8, 8, 4, 4, 2, 2};
+            size_t off = 0;
+            for (int p = 0; p < 7; ++p) {
+                const unsigned pw = (w + dx[p] - 1 - x0[p]) / dx[p], ph = (h + dy[p] - 1 - y0[p]) / dy[p];
+                if (w <= x0[p] || h <= y0[p] || pw == 0 || ph == 0) continue;
+                const size_t stride = ((size_t)pw * bits + 7) / 8;
+                if (off > raw.size() || !unfilter(raw.data() + off, raw.size() - off, ph, stride, bpp, img)) return "corrupt image data";
+                off += (size_t)ph * (stride + 1);
+                for (unsigned y = 0; y < ph; ++y)
+                    for (unsigned x = 0; x < pw; ++x) put(&img[y * stride], x, x0[p] + x * dx[p], y0[p] + y * dy[p]);
+            }
+        }
+    } catch (const std::bad_alloc &) {
+        rgba.clear();
+        return "out of memory while decoding";
     }
     return "";
 }
