@@ -329,10 +329,7 @@ MCPT_DI f3 importance_sample_ggx(float xi_x, float xi_y, float alpha, f3 n) {  /
     return normalized(tan_to_world(h, n));
 }
 
-MCPT_DI float get_ior(const MaterialRec &m, int ch) {  // Material.hpp:178-183
-    const float wl = wavelen(ch);
-    return m.iorA + m.iorB / (wl * wl);
-}
+MCPT_DI float get_ior(const MaterialRec &m, int ch) { return comp(m.ior, ch); }  // Material.hpp:178-183, tabulated per channel by the host
 
 MCPT_DI f3 mat_reflect(f3 I, f3 N) { return N * (2 * dot(N, I)) - I; }  // Material.hpp:195-197
 
@@ -378,8 +375,7 @@ MCPT_DI f3 mat_sample(const MaterialRec &m, f3 N, float xi_x, float xi_y) {  // 
 }
 
 MCPT_DI float eta_of(const MaterialRec &m, f3 wi, f3 N, int ch) {  // Material.hpp:299,318,360,393
-    const float ior = get_ior(m, ch);
-    return (dot(wi, N) > 0) ? ior : (float)(1. / (double)ior);
+    return (dot(wi, N) > 0) ? comp(m.ior, ch) : comp(m.inv_ior, ch);
 }
 
 MCPT_DI float mat_pdf(const MaterialRec &m, f3 wi, f3 wo, f3 N, int ch, bool isReflect) {  // Material.hpp:285-328 (rough branch)

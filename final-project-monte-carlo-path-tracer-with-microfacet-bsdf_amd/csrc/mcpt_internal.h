@@ -77,8 +77,13 @@ struct alignas(16) MaterialRec {  // Material.hpp:157-167
     float roughness, iorA, iorB, pad0;
     float refl[3], pad1;
     float emit[3], pad2;
+    // Per channel (WaveLen.hpp:7-18): getIor(lambda) = iorA + iorB / lambda^2 (Material.hpp:178-183) and the float (1. / ior) of
+    // Material.hpp:299,318,360,393, evaluated once on the host with the reference's expressions instead of per vertex and light
+    // sample on the device (a float and a double division each time)
+    float ior[3], pad3;
+    float inv_ior[3], pad4;
 };
-static_assert(sizeof(MaterialRec) == 64, "MaterialRec must be 64 bytes");
+static_assert(sizeof(MaterialRec) == 96, "MaterialRec must be 96 bytes");
 
 // Light table entry: one per emissive object, in Scene::Add order (Scene.hpp:106-108).
 struct alignas(16) LightRec {

@@ -39,7 +39,7 @@ MCPT_DI uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amd
 constexpr int kMaxAlloc = 9;
 constexpr int kMaxWaves = 16;
 struct BlockAllocShared {
-    uint32_t cnt[kMaxWaves][kMaxAlloc];
+    uint32_t cnt[kMaxWaves][kMaxAlloc];  // in: requests of wave w; out (after the first barrier): requests of the waves before w
     uint32_t base[kMaxAlloc];
 };
 
@@ -64,7 +64,11 @@ MCPT_DI void block_alloc_begin(BlockAllocShared &sh, const bool (&want)[N], cons
     for (int k = 0; k < N; ++k) {
         if (threadIdx.x == (unsigned)k) {  // lanes 0..N-1 of wave 0 issue their atomics in the same instruction
             uint32_t total = 0;
-            for (uint32_t w = 0; w < n_waves; ++w) total += sh.cnt[w][k];
+            for (uint32_t w = 0; w < n_waves; ++w) {  // counts -> exclusive prefix over the waves, in place
+                const uint32_t c = sh.cnt[w][k];
+                sh.cnt[w][k] = total;
+                total += c;
+            }
             uint32_t base = 0;
             if (total) {
                 const uint32_t amount = total * mult[k];
@@ -80,11 +84,7 @@ MCPT_DI void block_alloc_end(BlockAllocShared &sh, const uint32_t (&mult)[N], co
     const uint32_t wave = threadIdx.x >> 6;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        uint32_t before = 0;
-        for (uint32_t w = 0; w < wave; ++w) before += sh.cnt[w][k];
-        index[k] = sh.base[k] + (before + prefix[k]) * mult[k];
-    }
+    for (int k = 0; k < N; ++k) index[k] = sh.base[k] + (sh.cnt[wave][k] + prefix[k]) * mult[k];
 }
 
 template <int N>

@@ -325,6 +325,12 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, 
         }
         const V3 e = ld(m.emission);
         r.hasEmission = sqrtf(dot3(e, e)) > kEps;  // Material::hasEmission, Material.hpp:262
+        const float wavelen[3] = {0.700f, 0.5461f, 0.4358f};  // WaveLen.hpp:7-18
+        for (int k = 0; k < 3; ++k) {
+            const float wl = wavelen[k];
+            r.ior[k] = m.iorA + m.iorB / (wl * wl);          // Material.hpp:178-183
+            r.inv_ior[k] = (float)(1. / (double)r.ior[k]);   // Material.hpp:299 `1. / ior`
+        }
     }
 
     hs.tri_geom.resize(d.n_triangles);
