@@ -128,6 +128,7 @@ struct Knobs {
     // pure test hooks, compiled only into the checking build (-DMCPT_TEST_HOOKS, libmcpt_hip_check.so)
     uint32_t ring_start = 0;    // MCPT_RING_START: the free ring's counters start here (exercises the 2^32 wrap)
     int host_delay_us = 0;      // MCPT_HOST_DELAY_US: a slow host
+    uint64_t fake_free_mb = 0;  // MCPT_FAKE_FREE_MB: pretend that only this much device memory is free (exercises the pool shrink)
     void read() {
         auto off = [](const char *n) { const char *v = std::getenv(n); return v && v[0] == '0'; };
         overlap = !off("MCPT_OVERLAP");
@@ -141,6 +142,7 @@ struct Knobs {
 #ifdef MCPT_TEST_HOOKS
         if ((v = std::getenv("MCPT_RING_START"))) ring_start = (uint32_t)std::strtoul(v, nullptr, 0);
         if ((v = std::getenv("MCPT_HOST_DELAY_US"))) host_delay_us = std::atoi(v);
+        if ((v = std::getenv("MCPT_FAKE_FREE_MB"))) fake_free_mb = (uint64_t)std::max(1, std::atoi(v));
 #endif
     }
 };
@@ -662,6 +664,7 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            if (sc->knobs.fake_free_mb) free_b = std::min<size_t>(free_b, (size_t)sc->knobs.fake_free_mb << 20);  // (test hook)
             uint64_t held = 0;
             for (int k = 0; k < mcpt_scene::kMaxPools; ++k) held += (uint64_t)sc->pools[k].ws.pool * bytes_per_pool_path(sc->pools[k].ws.n_dir, sc->pools[k].ws.max_depth);
             const uint64_t result_b = (uint64_t)n_pix * s_pass * 3ull * 4ull * 2ull;

@@ -122,3 +122,14 @@ def test_random_configurations_do_not_depend_on_the_schedule(pkg, hip, hip_check
         hs = hip.HipScene(sd)
         parts = [hs.render(**kw, rank=r, nranks=nr, tile_size=ts)[0] for r in range(nr)]
         assert np.array_equal(ref, sum(parts[1:], parts[0]), equal_nan=True), (scene, w, h, kw, nr, ts)
+
+
+def test_pool_shrinks_to_the_free_memory(pkg, hip, hip_check, monkeypatch):
+    """The wavefront pool is sized from hipMemGetInfo: with little free memory (test hook of the checking build: MCPT_FAKE_FREE_MB) the
+    same frame is rendered with a smaller pool -- more wavefront iterations, identical pixels -- instead of failing to allocate."""
+    sd = pkg.scenes.chess_scene(width=480, height=270, spp=16)
+    ref, st0 = hip.HipScene(sd, library=hip_check).render(spp=16, seed=8, spp_per_pass=16)
+    monkeypatch.setenv("MCPT_FAKE_FREE_MB", "200")  # the default pool for this frame wants ~6 GB
+    fb, st = hip.HipScene(sd, library=hip_check).render(spp=16, seed=8, spp_per_pass=16)
+    assert np.array_equal(ref, fb, equal_nan=True)
+    assert st.iterations > 2 * st0.iterations and (st.vertices, st.shaded) == (st0.vertices, st0.shaded)

@@ -337,6 +337,15 @@ def test_full_size_properties(pkg, oracle, hip):
     assert st.samples == 1920 * 1080 * 4
     assert st.ref_scene_rays / st.samples == pytest.approx(8.80, rel=0.02)
     assert st.vertices / st.samples == pytest.approx(3.28, rel=0.01)
+    # BASELINE config 4 as the README labels it (direct light sample = 32) at the same full size: the partition property and the
+    # reference's call counts per sample (43.98 Scene::intersect calls per sample with 32 shadow rays per vertex)
+    full32, st32 = hs.render(spp=2, seed=11, n_dir_sample=32)
+    acc32 = np.zeros_like(full32)
+    for r in range(8):
+        acc32 += hs.render(spp=2, seed=11, n_dir_sample=32, tile_size=32, rank=r, nranks=8)[0]
+    assert np.array_equal(full32, acc32)
+    assert st32.ref_scene_rays / st32.samples == pytest.approx(43.98, rel=0.02)
+    assert st32.vertices / st32.samples == pytest.approx(3.28, rel=0.01)
     small = pkg.scenes.chess_scene(width=240, height=135, spp=32)
     ref, _ = oracle.OracleScene(small).render(spp=32, seed=5)
     blocks = full.reshape(135, 8, 240, 8, 3).mean(axis=(1, 3))
