@@ -24,4 +24,12 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WA
 done
 python3 $R/profiles/summarize_pmc.py $O/pmc_*.csv > $O/pmc_summary_no_overlap_64spp_step.json
 rm -f $O/pmc_*.csv
+# the other BASELINE configurations (bench lines only)
+python3 $R/bench.py --scene cornell_rc --width 784 --height 784 --steps 1 --spp-per-step 256 --cpu-spp 16 > $O/bench_config2_cornell_rc_784_spp256.json 2>> $O/bench.err || exit 1
+python3 $R/bench.py --steps 2 --no-cpu-baseline > $O/bench_config3_chess_spp512.json 2>> $O/bench.err || exit 1
+python3 $R/bench.py --n-dir 32 --no-cpu-baseline > $O/bench_config4_chess_spp2048_ndir32.json 2>> $O/bench.err || exit 1
+python3 $R/bench.py --scene cornell_demo --no-cpu-baseline > $O/bench_cornell_demo_1080p.json 2>> $O/bench.err || exit 1
+python3 $R/bench.py --scene chess_high --no-cpu-baseline > $O/bench_chess_high_sah.json 2>> $O/bench.err || exit 1
+MCPT_BVH=lbvh python3 $R/bench.py --scene chess_high --no-cpu-baseline > $O/bench_chess_high_lbvh.json 2>> $O/bench.err || exit 1
+echo "config benches done"
 ls -la $O
