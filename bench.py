@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--scene", default="chess", choices=["chess", "chess_high", "cornell_demo", "cornell_rc"],
                     help="chess_high: conf.json with model_quality high honoured (296 k triangles; the shipped executable cannot reach it)")
     ap.add_argument("--pool-paths", type=int, default=0)
+    ap.add_argument("--pass-steps", type=int, default=1,
+                    help="the library renders in passes of this many steps' samples (its per-pass result buffer); measured: no effect with the 60 Mi-path pool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline sample (full frame) on all cores; the 8-thread leg uses half")
     ap.add_argument("--serialized", action="store_true",
@@ -151,7 +153,7 @@ def main():
     def step(k, spp_total, accumulate, n_steps=1):
         return hs.render_device(fb.data_ptr(), stream.cuda_stream, spp=spp_step * n_steps, spp_total=spp_total,
                                 sample_offset=k * spp_step, accumulate=accumulate, seed=1, tile_size=32,
-                                rank=rank, nranks=world, n_dir_sample=args.n_dir, spp_per_pass=spp_step * world,
+                                rank=rank, nranks=world, n_dir_sample=args.n_dir, spp_per_pass=args.pass_steps * spp_step * world,
                                 pool_paths=args.pool_paths)
 
     def barrier():

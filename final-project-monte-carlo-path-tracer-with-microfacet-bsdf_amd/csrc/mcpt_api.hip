@@ -648,11 +648,11 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     }
     const uint32_t n_pix = sh.n_pix;
 
-    int s_pass = p.spp_per_pass > 0 ? p.spp_per_pass : 32;
-    s_pass = std::min(s_pass, p.spp);
-    while ((uint64_t)n_pix * s_pass * 3ull > 0xfffffff0ull && s_pass > 1) s_pass /= 2;
+    int s_pass_req = p.spp_per_pass > 0 ? p.spp_per_pass : 32;  // the caller's pass size: what the result buffer is sized for
+    while ((uint64_t)n_pix * s_pass_req * 3ull > 0xfffffff0ull && s_pass_req > 1) s_pass_req /= 2;
+    const int s_pass = std::min(s_pass_req, p.spp);
     const int max_depth = derive_max_depth(p);
-    uint64_t pool64 = p.pool_paths > 0 ? (uint64_t)p.pool_paths : (40ull << 20);  // measured: 24 Mi 3592, 36 M 3640, 42 M 3656 Msamples/s
+    uint64_t pool64 = p.pool_paths > 0 ? (uint64_t)p.pool_paths : (60ull << 20);  // measured (round 2): 28 Mi 4467, 40 Mi 4557, 60 Mi 4617, 80 Mi 4605 Msamples/s
     pool64 = std::max<uint64_t>(pool64, 3 * 256);
     // keep the clamp stack within 48 GiB
     while (pool64 * (uint64_t)max_depth * 16ull > (48ull << 30) && pool64 > 3 * 4096) pool64 /= 2;
@@ -667,7 +667,7 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
             if (sc->knobs.fake_free_mb) free_b = std::min<size_t>(free_b, (size_t)sc->knobs.fake_free_mb << 20);  // (test hook)
             uint64_t held = 0;
             for (int k = 0; k < mcpt_scene::kMaxPools; ++k) held += (uint64_t)sc->pools[k].ws.pool * bytes_per_pool_path(sc->pools[k].ws.n_dir, sc->pools[k].ws.max_depth);
-            const uint64_t result_b = (uint64_t)n_pix * s_pass * 3ull * 4ull * 2ull;
+            const uint64_t result_b = (uint64_t)n_pix * s_pass_req * 3ull * 4ull * 2ull;
             const uint64_t have = (uint64_t)free_b + held + sc->shared.result.bytes();
             const uint64_t budget = have * 8 / 10 > result_b ? have * 8 / 10 - result_b : 0;
             const uint64_t per = bytes_per_pool_path(p.n_dir_sample, max_depth);
@@ -690,9 +690,9 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     // two halves: a pass accumulates from one while the next pass fills the other (one half with a single pass)
     const size_t half_floats = (size_t)n_pix * s_pass * 3;
     const bool two_halves = n_pools == 1 && p.spp > s_pass;
-    // both halves are allocated even when this call needs one: a later call with more passes (a warm-up followed by the real
-    // frame) must not pay a multi-GB hipFree + hipMalloc
-    HIP_TRY(sh.result.alloc(half_floats * (n_pools == 1 ? 2 : 1)));
+    // both halves are allocated, for the REQUESTED pass size, even when this call needs less: a later call with more or longer passes
+    // (a warm-up followed by the real frame) must not pay a multi-GB hipFree + hipMalloc
+    HIP_TRY(sh.result.alloc((size_t)n_pix * s_pass_req * 3 * (n_pools == 1 ? 2 : 1)));
 
     RenderConst C;
     std::memset(&C, 0, sizeof C);
