@@ -436,6 +436,48 @@ MCPT_DI float mat_eval(const MaterialRec &m, f3 wi, f3 wo, f3 N, int ch, f2 uv, 
     return (float)(1. - (double)mat_fresnel(m, -wi, N, ch));
 }
 
+// Material::eval and Material::pdf of a ROUGH material for the same (wi, wo) in one go (Scene.cpp:140-143,167-170 calls both): the two
+// functions build the same half vector and the same D_GGX term (D depends on |N.h| only, so eval's sign-flipped h and pdf's unflipped one
+// give the same D); sharing them saves a normalisation and a D_GGX per continuing rough vertex.  Every expression is the one of
+// mat_eval / mat_pdf above, so the values are bit-identical to calling the two separately.
+MCPT_DI void mat_eval_pdf_rough(const MaterialRec &m, f3 wi, f3 wo, f3 N, int ch, f2 uv, bool isReflect, float &ev, float &pd) {
+    const float wiN = dot(wi, N), woN = dot(wo, N);
+    if (isReflect) {
+        const f3 hb = normalized(wi + wo);
+        const f3 h = (wiN > 0) ? hb : -hb;
+        const float D = D_GGX(h, N, m.roughness);
+        pd = D * dot(N, h) * (1.0f / (4.0f * fabsf(dot(h, wo))));   // Material.hpp:293-308
+        if (wiN * woN <= 0) {
+            ev = 0.f;
+            return;
+        }
+        const float F = (m.type == MCPT_ROUGH_CONDUCTOR) ? fresnel_schlick(m, fabsf(dot(h, wo)), uv, ch) : mat_fresnel(m, -wi, h, ch);
+        const float G = G_SmithGGX(wi, wo, h, m.roughness);
+        const float denom = 4.0f * fabsf(dot(N, wi)) * fabsf(dot(N, wo)) + kEps;
+        ev = F * D * G / denom;                                      // Material.hpp:338-352
+        return;
+    }
+    const float eta = eta_of(m, wi, N, ch);
+    const f3 hv = (-wi) - wo * eta;
+    const f3 hb = normalized(hv);
+    const float D = D_GGX(hb, N, m.roughness);
+    const float d1 = dot(hv, hv);
+    pd = D * dot(N, hb) * (eta * eta * fabsf(dot(hb, wo)) / d1);     // Material.hpp:309-327
+    if (m.type == MCPT_ROUGH_CONDUCTOR || wiN * woN >= 0) {
+        ev = 0.f;
+        return;
+    }
+    const f3 h = dot(hb, N) > 0 ? hb : -hb;
+    const float F = mat_fresnel(m, -wi, h, ch);
+    const float G = G_SmithGGX(wi, wo, h, m.roughness);
+    const float hol = dot(h, wi);
+    const float hov = dot(h, wo);
+    float den = hol + eta * hov;
+    den *= den;
+    den *= fabsf(dot(N, wi) * dot(N, wo));
+    ev = (1.0f - F) * D * G * eta * eta * fabsf(hol * hov) / den;   // Material.hpp:354-372
+}
+
 // ---------------------------------------------------------------- environment, Scene.hpp:60-99
 MCPT_DI f3 sample_env(const DevScene &S, f3 dir) {
     if (S.env_w <= 0) return mk3(S.background[0], S.background[1], S.background[2]);

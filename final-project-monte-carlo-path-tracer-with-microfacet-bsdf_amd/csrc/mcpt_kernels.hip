@@ -884,12 +884,12 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
         else p2 = (dot(wo, mfn) < 0) ? (p + n * kEps) : (p - n * kEps);            // Scene.cpp:151-155
         if (has_cont) {
             wi = isReflect ? mat_reflect(wo, mfn) : mat_refract(m, rd, mfn, ch);   // Scene.cpp:132,159
-            ev = mat_eval(m, wi, wo, n, ch, uv, isReflect);
             if (m.isDirac) {
+                ev = mat_eval(m, wi, wo, n, ch, uv, isReflect);
                 aw = -1.f;
             } else {
                 aw = fabsf(dot(wo, n));
-                pd = mat_pdf(m, wi, wo, n, ch, isReflect);
+                mat_eval_pdf_rough(m, wi, wo, n, ch, uv, isReflect, ev, pd);  // Material::eval and ::pdf sharing h and D
             }
         }
     }
