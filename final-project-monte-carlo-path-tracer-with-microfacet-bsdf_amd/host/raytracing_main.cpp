@@ -103,6 +103,14 @@ int main(int argc, char **argv) {
         if (iorB >= 0) m->iorB = iorB;
         return materials[name] = m;
     };
+    // A material name that is not a preset: the reference indexes its map with it (main.cpp:232,259-262,283) and dereferences the null
+    // pointer the map hands back.  Here the name is reported and the default of an unset key, rough_plastic, is used.
+    [[maybe_unused]] auto named = [&](const std::string &name) -> Material * {
+        auto it = materials.find(name);
+        if (it != materials.end() && it->second) return it->second;
+        std::cerr << "Unknown material \"" << name << "\": using rough_plastic" << std::endl;
+        return materials["rough_plastic"];
+    };
     preset("rough_red_conductor", ROUGH_CONDUCTOR, 0.1f, {1.0f, 0.0f, 0.0f});
     preset("rough_white_conductor", ROUGH_CONDUCTOR, 0.4f, {0.725f, 0.71f, 0.68f});
     preset("green_mirror", ROUGH_CONDUCTOR, 0.01f, {0.14f, 1.0f, 0.14f});
@@ -173,7 +181,7 @@ int main(int argc, char **argv) {
                 else if (is_v3(cs["envMap"])) scene.backgroundColor = v3(cs["envMap"]);
             }
             if (is_v3(cs["kingPosition"])) kingPosition = v3(cs["kingPosition"]);
-            if (cs["kingMaterial"].is_string()) kingMaterial = materials[cs["kingMaterial"].as_string()];
+            if (cs["kingMaterial"].is_string()) kingMaterial = named(cs["kingMaterial"].as_string());
             if (cs.contains("soldierLeftRowPosition") && cs.contains("soldierRightRowPosition") && cs.contains("soldierMaterials")) {
                 const Json &lrow = cs["soldierLeftRowPosition"], &rrow = cs["soldierRightRowPosition"];
                 const float xs = cs["soldierXSpacing"].as_float(), ys = cs["soldierYSpacing"].as_float(), zs = cs["soldierZSpacing"].as_float();
@@ -183,8 +191,8 @@ int main(int argc, char **argv) {
                     const float xo = i * xs, yo = i * ys, zo = i * zs;
                     const Vector3f lp(lrow[0].as_float() + xo, lrow[1].as_float() + yo, lrow[2].as_float() + zo);
                     const Vector3f rp(rrow[0].as_float() + xo, rrow[1].as_float() + yo, rrow[2].as_float() + zo);
-                    Material *lm = ((size_t)i < names.size()) ? materials[names[i].as_string()] : materials["rough_plastic"];
-                    Material *rm = ((size_t)(i + count) < names.size()) ? materials[names[i + count].as_string()] : materials["rough_plastic"];
+                    Material *lm = ((size_t)i < names.size()) ? named(names[i].as_string()) : materials["rough_plastic"];
+                    Material *rm = ((size_t)(i + count) < names.size()) ? named(names[i + count].as_string()) : materials["rough_plastic"];
                     scene.Add(new MeshTriangle(soldier_model, lm, lp));
                     scene.Add(new MeshTriangle(soldier_model, rm, rp));
                 }
@@ -192,7 +200,7 @@ int main(int argc, char **argv) {
             if (is_v3(cs["lightPosition"])) lightPosition = v3(cs["lightPosition"]);
             if (cs["lightBrightness"].is_number_float()) brightness_scale = cs["lightBrightness"].as_float();
             if (cs["floorMaterial"].is_string()) {
-                floorMaterial = materials[cs["floorMaterial"].as_string()];
+                floorMaterial = named(cs["floorMaterial"].as_string());
                 floorMaterial->textured = cs["floor_isTextured"].as_bool();
             }
         }

@@ -167,3 +167,39 @@ def test_checkpoint_and_resume(pkg, hip, host_bins, tmp_path):
     assert p.returncode == 0 and "resuming" not in p.stdout
     fb, _ = hip.HipScene(pkg.scenes.cornell_demo(40, 30, 4)).render(spp=4, seed=1)
     assert np.array_equal(pkg.pngio.read_png(str(tmp_path / "small.png"))[:, :, :3], pkg.pngio.tonemap_u8(fb))
+
+
+def test_host_parsers_under_asan(pkg, hip, tmp_path):
+    """conf.json reader (json_min.hpp), OBJ reader and scene flattening of the C++ host under AddressSanitizer + UBSan, on the shipped
+    configuration and on damaged ones (truncated / random bytes): an error message or the defaults, never a memory error."""
+    exe = str(tmp_path / "RayTracing_asan")
+    pkgdir = os.path.dirname(HOST)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off",
+                           os.path.join(HOST, "raytracing_main.cpp"), os.path.join(HOST, "mcpt_host.cpp"), "-o", exe,
+                           "-L" + pkgdir, "-lmcpt_hip", "-Wl,-rpath," + pkgdir])
+    text = json.dumps(pkg.scenes.DEFAULT_CONF, indent=1)
+    rng = np.random.default_rng(4)
+    variants = [text, text[:len(text) // 2], text.replace("[", "{", 3), '{"camera": {"width": "x", "position": [1, 2]}, "scene": {"soldierMaterials": 5}}', ""]
+    for _ in range(12):
+        b = bytearray(text.encode())
+        for _ in range(int(rng.integers(1, 8))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(32, 127))
+        variants.append(b.decode("ascii", "replace"))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")  # (the reference's main leaks its scene objects by design; so does the mirror)
+    for k, v in enumerate(variants):
+        (tmp_path / "conf.json").write_text(v)
+        p = subprocess.run([exe, "--models", MODELS, "--dump", str(tmp_path / "d.bin")], cwd=str(tmp_path), capture_output=True, text=True, env=env)
+        assert p.returncode in (0, 1) and "Sanitizer" not in p.stderr and "runtime error" not in p.stderr, (k, p.stderr[-3000:])
+    # a damaged OBJ file
+    models = tmp_path / "models"
+    os.makedirs(models / "cornellbox")
+    for f in os.listdir(MODELS):
+        src = os.path.join(MODELS, f)
+        if os.path.isfile(src):
+            data = open(src, "rb").read()
+            if f == "low_soldier.obj":
+                data = data[:len(data) // 3] + b"\nf 1/2/3 999999 -5\nv 1 2\nf\nvt\n" + data[len(data) // 3:len(data) // 2]
+            open(models / f, "wb").write(data)
+    (tmp_path / "conf.json").write_text(text)
+    p = subprocess.run([exe, "--models", str(models), "--dump", str(tmp_path / "d.bin")], cwd=str(tmp_path), capture_output=True, text=True, env=env)
+    assert p.returncode in (0, 1) and "Sanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-3000:]
