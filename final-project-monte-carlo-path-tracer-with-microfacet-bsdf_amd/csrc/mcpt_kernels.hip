@@ -383,6 +383,143 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n
     }
 }
 
+// k_trace_closest with lane refill.  Rays of one wave finish at different times (59 % lane utilisation with one ray per lane,
+// profiles/r02_traversal_stats.txt).  Here a wave owns a chunk of kRaysPerLane x 64 consecutive rays and, at the top of every round
+// of the speculative loop, lanes whose ray has finished store its hit and -- once at least kRefillMin lanes are idle -- take the next
+// rays of the chunk (ballot + prefix count: no atomics, no persistent grid: the grid is still one workgroup per 1024 rays).
+// The common configuration only (quantised nodes, no instancing); a ray with a zero direction component is traced on the spot by
+// the generic path.  Same tests per ray as traverse_loop<kClosest, STK, true, true, false>, hence the same hits.
+#ifndef MCPT_REFILL_MIN
+#define MCPT_REFILL_MIN 16
+#endif
+#ifndef MCPT_RAYS_PER_LANE
+#define MCPT_RAYS_PER_LANE 4
+#endif
+constexpr uint32_t kRaysPerLane = MCPT_RAYS_PER_LANE, kRefillMin = MCPT_REFILL_MIN;
+// Occupancy: the refill state costs registers (79 VGPRs unconstrained = 6 waves per SIMD).  Bounding the kernel to 7 waves per SIMD
+// (72 VGPRs, 14 spilled) is the measured optimum: frame 4617 (one ray per lane) -> 4645 (unconstrained) -> 4695 (7 waves) ->
+// 4620 (8 waves, 42 spills); refill thresholds 8 / 16 / 32 and 2 / 4 / 8 rays per lane: 4670 / 4695 / 4690 and 4595 / 4695 / 4705.
+#ifndef MCPT_REFILL_WAVES
+#define MCPT_REFILL_WAVES 7
+#endif
+template <int STK>
+__global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k_trace_closest_refill(  // (deeper stacks: LDS bounds the occupancy below 7 anyway)DevScene S, uint32_t n_host, const uint32_t *__restrict__ n_dev,
+                                                                 const float4 *__restrict__ ray_o, const float4 *__restrict__ ray_d,
+                                                                 uint4 *__restrict__ hit) {
+    __shared__ int32_t stk[STK][kBlock];
+    const int tid = threadIdx.x;
+    const uint32_t wave = (uint32_t)tid >> 6;
+    const uint32_t n = n_dev ? *n_dev : n_host;
+    constexpr uint32_t kChunk = 64u * kRaysPerLane;
+    for (uint32_t chunk = blockIdx.x * (kBlock / 64) + wave; (unsigned long long)chunk * kChunk < n; chunk += gridDim.x * (kBlock / 64)) {
+        uint32_t next = chunk * kChunk;
+        const uint32_t end = min(n, next + kChunk);
+        int32_t my = -1;  // index of the ray this lane is tracing
+        Ray r = make_ray(mk3(0, 0, 0), mk3(0, 0, 1));
+        QRay qr = make_qray(S, r);
+        float lim = INFINITY;
+        double best_t = DBL_MAX;
+        int32_t best_prim = -1;
+        uint32_t best_mat = 0;
+        int32_t cur = kNoWork, leaf = kNoWork;
+        int sp = 0;
+        while (true) {
+            // ---- finished lanes: store, refill
+            const bool idle = cur == kNoWork && leaf == kNoWork;
+            if (idle && my >= 0) {
+                hit[my] = pack_hit(best_t, best_prim, best_mat);
+                my = -1;
+            }
+            const unsigned long long im = __ballot(idle);
+            const uint32_t n_idle = (uint32_t)__popcll(im);
+            if (next < end && n_idle >= kRefillMin) {
+                const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+                if (idle && idx < end) {
+                    r = make_ray(ld3(ray_o[idx]), ld3(ray_d[idx]));
+                    if (!ray_is_plain(r)) {  // rare (a zero direction component): the NaN-faithful generic path, right away
+                        const TraceResult tr = traverse<false, STK>(S, r, 0.f, stk, tid);
+                        hit[idx] = pack_hit(tr.t, tr.prim, tr.mat_bits);
+                    } else {
+                        my = (int32_t)idx;
+                        qr = make_qray(S, r);
+                        lim = INFINITY;
+                        best_t = DBL_MAX;
+                        best_prim = -1;
+                        best_mat = 0;
+                        sp = 0;
+                        float tm, tx;
+                        if (box_hit<true>(S.root_min, S.root_max, r, tm, tx)) {
+                            if (S.root >= 0) cur = S.root;
+                            else leaf = S.root;  // a scene of one primitive
+                        }
+                    }
+                }
+                next += n_idle;
+            }
+            if (!__any(my >= 0)) break;
+            // ---- phase 1: inner nodes (see traverse_loop)
+            while (true) {
+                if (cur >= 0) {
+                    const uint4 *np = reinterpret_cast<const uint4 *>(S.qnodes + cur);
+                    const uint4 a = np[0], b = np[1];
+                    const int32_t left = (int32_t)b.z, right = (int32_t)b.w;
+                    float tl = 0.f, tr = 0.f, txl = 0.f, txr = 0.f;
+                    bool hl = qbox_hit<true>(S, r, qr, a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16, a.z & 0xffffu, a.z >> 16, tl, txl);
+                    bool hr = qbox_hit<true>(S, r, qr, a.w & 0xffffu, a.w >> 16, b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16, tr, txr);
+                    hl = hl && !(tl > lim);
+                    hr = hr && !(tr > lim);
+                    if (hl && hr) {
+                        const bool swap = tr < tl;
+                        const int32_t nearc = swap ? right : left, farc = swap ? left : right;
+                        if (sp < STK) stk[sp++][tid] = farc;
+                        cur = nearc;
+                    } else if (hl) {
+                        cur = left;
+                    } else if (hr) {
+                        cur = right;
+                    } else {
+                        cur = (sp == 0) ? kNoWork : stk[--sp][tid];
+                    }
+                    if (cur < 0 && cur != kNoWork && leaf == kNoWork) {
+                        leaf = cur;
+                        cur = (sp == 0) ? kNoWork : stk[--sp][tid];
+                    }
+                }
+                if (__popcll(__ballot(leaf == kNoWork && cur >= 0)) <= kLeafVote) break;
+            }
+            // ---- phase 2: the parked leaf
+            if (leaf != kNoWork) {
+                const int32_t prim = ~leaf;
+                double t = 0, u, v;
+                bool h;
+                uint32_t mb;
+                if (prim < S.n_tri) {
+                    const TriGeom g = S.tri_geom[prim];
+                    mb = g.mat_bits;
+                    h = tri_hit(g, r, t, u, v);
+                } else {
+                    float ts = 0.f;
+                    const SphereRec sph = S.spheres[prim - S.n_tri];
+                    mb = sph.mat_bits;
+                    h = sphere_hit(sph, r, ts);
+                    t = (double)ts;
+                }
+                if (h && (t < best_t || (t == best_t && prim > best_prim))) {
+                    best_t = t;
+                    best_prim = prim;
+                    best_mat = mb;
+                    lim = (float)(t + (fabs(t) * 1e-4 + 1e-2));
+                }
+                leaf = kNoWork;
+                if (cur < 0 && cur != kNoWork) {
+                    leaf = cur;
+                    cur = (sp == 0) ? kNoWork : stk[--sp][tid];
+                }
+            }
+        }
+    }
+}
+
 // Shadow queue consumer: a fixed grid strides over the queue, whose length is only known on the device.
 // Items [0, n_found) are the front of the arrays (light sample already found: occluder search only), the next n_window
 // items are read from the back (window search first), so that the long occluder searches fill whole waves.
@@ -1153,6 +1290,17 @@ void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const
 void launch_trace_closest(const DevScene &S, uint32_t n, const uint32_t *n_dev, const float4 *ray_o, const float4 *ray_d, uint4 *hit,
                           hipStream_t s) {
     if (n == 0) return;
+#ifndef MCPT_NO_REFILL
+    if (S.qnodes && !S.inst) {  // the common configuration: lanes refill from the wave's chunk of rays
+        const dim3 g((n + kBlock * kRaysPerLane - 1) / (kBlock * kRaysPerLane)), b(kBlock);
+        if (S.height <= 16) hipLaunchKernelGGL((k_trace_closest_refill<16>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
+        else if (S.height <= 20) hipLaunchKernelGGL((k_trace_closest_refill<20>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
+        else if (S.height <= 24) hipLaunchKernelGGL((k_trace_closest_refill<24>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
+        else if (S.height <= 32) hipLaunchKernelGGL((k_trace_closest_refill<32>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
+        else hipLaunchKernelGGL((k_trace_closest_refill<kMaxBvhHeight>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
+        return;
+    }
+#endif
     const dim3 g(blocks(n)), b(kBlock);
     if (S.height <= 16) hipLaunchKernelGGL((k_trace_closest<16>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
     else if (S.height <= 20) hipLaunchKernelGGL((k_trace_closest<20>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
