@@ -399,11 +399,12 @@ constexpr uint32_t kRaysPerLane = MCPT_RAYS_PER_LANE, kRefillMin = MCPT_REFILL_M
 // Occupancy: the refill state costs registers (79 VGPRs unconstrained = 6 waves per SIMD).  Bounding the kernel to 7 waves per SIMD
 // (72 VGPRs, 14 spilled) is the measured optimum: frame 4617 (one ray per lane) -> 4645 (unconstrained) -> 4695 (7 waves) ->
 // 4620 (8 waves, 42 spills); refill thresholds 8 / 16 / 32 and 2 / 4 / 8 rays per lane: 4670 / 4695 / 4690 and 4595 / 4695 / 4705.
+// (Stacks deeper than 20 entries: LDS bounds the occupancy below 7 anyway, so no register bound there.)
 #ifndef MCPT_REFILL_WAVES
 #define MCPT_REFILL_WAVES 7
 #endif
 template <int STK>
-__global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k_trace_closest_refill(  // (deeper stacks: LDS bounds the occupancy below 7 anyway)DevScene S, uint32_t n_host, const uint32_t *__restrict__ n_dev,
+__global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k_trace_closest_refill(DevScene S, uint32_t n_host, const uint32_t *__restrict__ n_dev,
                                                                  const float4 *__restrict__ ray_o, const float4 *__restrict__ ray_d,
                                                                  uint4 *__restrict__ hit) {
     __shared__ int32_t stk[STK][kBlock];
