@@ -225,7 +225,12 @@ def main():
         avg_ms = ms / n_launch
         bytes_per_launch = per_unit * units / n_launch
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        # PMC bytes per launch were measured on the serialised profile's launches; scale them to this run's launch size (bytes per
+        # ray / vertex are what carries over)
         traffic = prof.get(dom)
+        ser_units = ser.get(dom, {}).get("units_per_launch")
+        if traffic and ser_units:
+            traffic = int(traffic * (units / n_launch) / ser_units)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": int(n_launch), "units_per_launch": round(units / n_launch, 1),
@@ -238,7 +243,8 @@ def main():
                     "valu_busy_frac": ser.get(dom, {}).get("valu_busy_frac"),
                     "serialized": ser.get(dom),
                     "kernel_ms": {k: round(v[0], 2) for k, v in kern.items()},
-                    "kernel_launches": {k: int(v[1]) for k, v in kern.items()}}
+                    "kernel_launches": {k: int(v[1]) for k, v in kern.items()},
+                    "kernel_units": {k: int(v[2]) for k, v in kern.items()}}
     ref_bytes_per_sample = (BYTES_PER_RAY * tot_ref_rays + BYTES_PER_VERTEX * tot_vertices) / tot_samples + BYTES_PER_SAMPLE
     ref_gbs = value * 1e6 * ref_bytes_per_sample / 1e9
     traced_bytes_per_sample = (BYTES_PER_RAY * (tot_closest + tot_shadow) + BYTES_PER_VERTEX * tot_vertices) / tot_samples + BYTES_PER_SAMPLE

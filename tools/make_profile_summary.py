@@ -48,6 +48,11 @@ def main(d, tag):
         if "SQ_INSTS_VALU" in e:
             t = [v for c, v in e["ms_profiled"].items() if "SQ_INSTS_VALU" in c][0]
             row["valu_busy_frac"] = round(e["SQ_INSTS_VALU"] * CYCLES_PER_VALU / (SIMDS * CLOCK_HZ) / (t * 1e-3), 3)
+        ku, kl = bench["roofline"].get("kernel_units", {}), bench["roofline"].get("kernel_launches", {})
+        if ku.get(k) and kl.get(k):
+            row["units_per_launch"] = round(ku[k] / kl[k], 1)
+            if row["hbm_bytes_per_launch"]:
+                row["hbm_bytes_per_unit"] = round(row["hbm_bytes_per_launch"] / row["units_per_launch"], 1)
         if row["hbm_bytes_per_launch"]:
             row["hbm_GBps"] = round(row["hbm_bytes_per_launch"] / (row["avg_launch_ms"] * 1e-3) / 1e9, 1)
         ser[k] = row
