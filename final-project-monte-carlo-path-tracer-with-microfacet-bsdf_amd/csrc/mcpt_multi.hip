@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -111,6 +112,10 @@ int mcpt_group_create(const mcpt_scene_desc *desc, int n_devices, const int *dev
     g->streams.assign(n_devices, nullptr);
     g->same_device = true;
     for (int i = 1; i < n_devices; ++i) g->same_device = g->same_device && devices[i] == devices[0];
+    // Diagnostic: MCPT_GROUP_FORCE_RCCL=1 sends a ONE-device group through the RCCL merge as well (a communicator of one rank), so
+    // that the library loading, communicator set-up and the ncclReduce call can be exercised on a one-GPU box.
+    const char *force = std::getenv("MCPT_GROUP_FORCE_RCCL");
+    if (n_devices == 1 && force && force[0] == '1') g->same_device = false;
     if (!g->same_device)
         for (int i = 0; i < n_devices; ++i)
             for (int j = 0; j < i; ++j)

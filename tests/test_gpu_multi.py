@@ -35,6 +35,21 @@ def test_group_rehearsal_is_bit_identical_to_one_gpu(pkg, hip):
         g.close()
 
 
+def test_rccl_merge_path_with_a_communicator_of_one(pkg, hip, monkeypatch):
+    """The RCCL leg of mcpt_group_render (dlopen of librccl, ncclCommInitAll, ncclGroupStart / ncclReduce / ncclGroupEnd on the group's
+    stream) needs distinct devices; MCPT_GROUP_FORCE_RCCL=1 runs it for a group of ONE device (a one-rank communicator), which is what a
+    one-GPU box can exercise of it.  The frame must be the plain one."""
+    sd = pkg.scenes.cornell_demo(64, 48, 4)
+    ref, _ = hip.HipScene(sd).render(spp=4, seed=2)
+    monkeypatch.setenv("MCPT_GROUP_FORCE_RCCL", "1")
+    g = hip.HipGroup(sd, [0])
+    fb, st = g.render(spp=4, seed=2)
+    assert np.array_equal(ref, fb, equal_nan=True) and st.samples == 64 * 48 * 4
+    fb2, _ = g.render(fb=fb.copy(), spp=4, spp_total=8, sample_offset=4, accumulate=1, seed=2)  # the communicator is reused
+    assert np.isfinite(fb2).all()
+    g.close()
+
+
 def test_group_argument_errors(pkg, hip):
     sd = pkg.scenes.cornell_rc(32, 32, 1)
     with pytest.raises(hip.McptError):
