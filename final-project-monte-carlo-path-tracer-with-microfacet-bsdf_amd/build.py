@@ -12,8 +12,8 @@ LIB = os.path.join(HERE, "libmcpt_hip.so")
 # MCPT_HOST_DELAY_US) compiled in.  Tests load it explicitly; the product library carries neither.
 LIB_CHECK = os.path.join(HERE, "libmcpt_hip_check.so")
 CHECK_DEFINES = ["-DMCPT_TEST_HOOKS", "-DMCPT_CHECK_DIRECT_SKIP"]
-SOURCES = ["mcpt_scene.cpp", "mcpt_kernels.hip", "mcpt_api.hip", "mcpt_multi.hip", "mcpt_lbvh.hip"]
-HEADERS = ["mcpt_internal.h", "mcpt_device.h", "mcpt_fmath.h", "mcpt_kernels.h", "mcpt_lbvh.h", os.path.join("..", "..", "include", "mcpt.h")]
+SOURCES = ["mcpt_scene.cpp", "mcpt_kernels.hip", "mcpt_api.hip", "mcpt_multi.hip", "mcpt_lbvh.hip", "mcpt_cull.hip"]
+HEADERS = ["mcpt_internal.h", "mcpt_device.h", "mcpt_fmath.h", "mcpt_kernels.h", "mcpt_lbvh.h", "mcpt_cull.h", os.path.join("..", "..", "include", "mcpt.h")]
 # -ffp-contract=off: the arithmetic contract of csrc/mcpt_device.h (no FMA contraction, so the same seeds
 # give the same paths as the CPU restatement).  f32 divide/sqrt stay correctly rounded (hipcc default).
 # -fno-slp-vectorize: the SLP vectoriser pairs scalar f32 adds/muls into v_pk_*_f32, which issue slower than the two
@@ -47,7 +47,7 @@ def _compile(lib, defines, suffix, verbose):
         subprocess.check_call(cmd)
         return o
 
-    with ThreadPoolExecutor(max_workers=5) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(one, SOURCES))
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"]
     if verbose:

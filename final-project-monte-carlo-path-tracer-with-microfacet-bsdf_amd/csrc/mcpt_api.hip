@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "mcpt_kernels.h"
+#include "mcpt_cull.h"
 #include "mcpt_lbvh.h"
 
 using namespace mcpt;
@@ -108,11 +109,14 @@ struct Workspace {
 struct SharedBufs {
     DevBuf<float> result;
     DevBuf<uint32_t> pixel_list, key_pixel, key_sample;
+    DevBuf<uint32_t> culled_list, cull_count;  // pixel_list partitioned: [may hit | background only] (csrc/mcpt_cull.hip)
+    DevBuf<uint8_t> cull_flags, cull_temp;
     DevBuf<int32_t> key_channel;
     int pix_key[5] = {0, 0, 0, 0, 0};  // (W, H, tile, rank, nranks) of the pixel list currently in HBM
     uint32_t n_pix = 0;
     void release() {
         result.release(); pixel_list.release(); key_pixel.release(); key_sample.release(); key_channel.release();
+        culled_list.release(); cull_count.release(); cull_flags.release(); cull_temp.release();
     }
 };
 
@@ -128,12 +132,14 @@ struct Knobs {
     // pure test hooks, compiled only into the checking build (-DMCPT_TEST_HOOKS, libmcpt_hip_check.so)
     uint32_t ring_start = 0;    // MCPT_RING_START: the free ring's counters start here (exercises the 2^32 wrap)
     int host_delay_us = 0;      // MCPT_HOST_DELAY_US: a slow host
+    bool sky_cull = true;       // MCPT_SKY_CULL=0: trace the pixels that can only see the background too
     uint64_t fake_free_mb = 0;  // MCPT_FAKE_FREE_MB: pretend that only this much device memory is free (exercises the pool shrink)
     void read() {
         auto off = [](const char *n) { const char *v = std::getenv(n); return v && v[0] == '0'; };
         overlap = !off("MCPT_OVERLAP");
         queue_ahead = !off("MCPT_QUEUE_AHEAD");
         timing = !off("MCPT_TIMING");
+        sky_cull = !off("MCPT_SKY_CULL");
         const char *v;
         if ((v = std::getenv("MCPT_POOLS"))) pools = (v[0] == '2') ? 2 : 1;
         if ((v = std::getenv("MCPT_DRAIN_BATCH"))) drain_batch = std::max(1, std::atoi(v));
@@ -646,7 +652,30 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
         if (!pix.empty()) HIP_TRY(hipMemcpy(sh.pixel_list.p, pix.data(), pix.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         std::memcpy(sh.pix_key, pk, sizeof pk);
     }
-    const uint32_t n_pix = sh.n_pix;
+    const uint32_t n_pix_owned = sh.n_pix;
+    const CameraConst cc = make_camera(*cam);
+    const float spp_total = (float)(p.spp_total > 0 ? p.spp_total : p.spp);
+    if (!p.accumulate) HIP_TRY(hipMemsetAsync(fb_dev, 0, (size_t)W * H * 3 * sizeof(float), st));
+
+    // Pixels that can only see the background (no environment map: every sample returns the same constant) are finished here,
+    // without a ray; the wavefront loop below runs over the others.  csrc/mcpt_cull.hip has the conservative bound.
+    uint32_t n_pix = n_pix_owned;
+    const uint32_t *pixel_list = sh.pixel_list.p;
+    if (sc->knobs.sky_cull && sc->view.env_w <= 0 && n_pix_owned > 0) {
+        const size_t tb = cull_temp_bytes(n_pix_owned);
+        HIP_TRY(sh.culled_list.alloc(n_pix_owned));
+        HIP_TRY(sh.cull_flags.alloc(n_pix_owned));
+        HIP_TRY(sh.cull_temp.alloc(tb));
+        HIP_TRY(sh.cull_count.alloc(1));
+        uint32_t n_trace = n_pix_owned;
+        HIP_TRY(cull_sky_pixels(sc->view, cc, sh.pixel_list.p, n_pix_owned, sh.culled_list.p, sh.cull_flags.p, sh.cull_temp.p, tb, sh.cull_count.p,
+                                &n_trace, st));
+        if (n_trace < n_pix_owned) {
+            launch_sky_fill(sh.culled_list.p + n_trace, n_pix_owned - n_trace, sc->view.background, p.spp, spp_total, fb_dev, st);
+            n_pix = n_trace;
+            pixel_list = sh.culled_list.p;
+        }
+    }
 
     int s_pass_req = p.spp_per_pass > 0 ? p.spp_per_pass : 32;  // the caller's pass size: what the result buffer is sized for
     while ((uint64_t)n_pix * s_pass_req * 3ull > 0xfffffff0ull && s_pass_req > 1) s_pass_req /= 2;
@@ -680,12 +709,12 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     if ((uint64_t)n_pix * s_pass < min_work || pool64 / 2 < 3 * 256) n_pools = 1;
     const uint32_t pool = (uint32_t)(pool64 / n_pools / 3 * 3);
 
-    if (!p.accumulate) HIP_TRY(hipMemsetAsync(fb_dev, 0, (size_t)W * H * 3 * sizeof(float), st));
-    if (n_pix == 0) {
+    if (n_pix_owned == 0) {
         HIP_TRY(hipStreamSynchronize(st));
         if (stats) std::memset(stats, 0, sizeof *stats);
         return MCPT_OK;
     }
+    // (n_pix == 0 with owned pixels: every one of them was culled; the loop below then has no samples to issue and falls through)
     for (int k = 0; k < n_pools; ++k) HIP_TRY(ensure_workspace(sc->pools[k], pool, p.n_dir_sample, max_depth));
     // two halves: a pass accumulates from one while the next pass fills the other (one half with a single pass)
     const size_t half_floats = (size_t)n_pix * s_pass * 3;
@@ -702,13 +731,10 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     C.enable_shadow = p.enable_shadow;
     C.seed = p.seed;
     C.mode = 0;
-    C.pixel_list = sh.pixel_list.p;
+    C.pixel_list = pixel_list;
     C.max_depth = max_depth;
     C.result[0] = sh.result.p;
     C.result[1] = two_halves ? sh.result.p + half_floats : sh.result.p;
-    const CameraConst cc = make_camera(*cam);
-    const float spp_total = (float)(p.spp_total > 0 ? p.spp_total : p.spp);
-
     for (int k = 0; k < n_pools; ++k) {
         sc->pools[k].timer.reset();
         sc->pools[k].timer.enabled = sc->knobs.timing;
@@ -722,7 +748,7 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
             const int s_now = std::min(s_pass, p.spp - k0);
             plan.push_back(PassPlan{0u, n_pix * (uint32_t)s_now, s_now, p.sample_offset + k0});
         }
-        AccumPlan acc{fb_dev, spp_total, n_pix, sh.pixel_list.p, {C.result[0], C.result[1]}};
+        AccumPlan acc{fb_dev, spp_total, n_pix, pixel_list, {C.result[0], C.result[1]}};
         const int rc = drained(run_wavefront(sc, sc->pools[0], C, &cc, plan, &acc, st, tot[0]));
         if (rc != MCPT_OK) return rc;
     } else {
@@ -753,7 +779,7 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
             if (c1.rc != MCPT_OK) return drained(fail(c1.rc, c1.err));
             Timer &T0 = sc->pools[0].timer;
             int ev = T0.begin(st);
-            launch_accumulate(C.result[0], sh.pixel_list.p, n_pix, s_now, spp_total, fb_dev, st);
+            launch_accumulate(C.result[0], pixel_list, n_pix, s_now, spp_total, fb_dev, st);
             T0.end(ev, K_RESOLVE, st);
         }
     }
@@ -779,7 +805,9 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     }
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
-        stats->samples = (uint64_t)n_pix * p.spp;
+        // (culled pixels count like traced ones: the reference runs one camera ray and three castRay invocations, each with one
+        // Scene::intersect, for every sample of them too)
+        stats->samples = (uint64_t)n_pix_owned * p.spp;
         stats->paths = 3 * stats->samples;
         stats->vertices = stats->paths + pushes;
         stats->shaded = sum.shaded;
@@ -788,7 +816,7 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
         stats->direct_vertices = sum.direct;
         // Scene::intersect calls of the reference: one per castRay invocation (Scene.cpp:87), n_dir per shaded
         // vertex (Scene.cpp:73), one look-ahead per vertex that survives roulette (Scene.cpp:134,161).
-        const uint64_t cont = sum.closest - stats->samples;
+        const uint64_t cont = sum.closest - (uint64_t)n_pix * p.spp;  // closest-hit rays beyond the primary rays actually traced
         stats->ref_scene_rays = stats->vertices + (uint64_t)p.n_dir_sample * sum.shaded + cont;
         stats->iterations = sum.iterations;
         stats->overflow_paths = overflow;
