@@ -207,9 +207,13 @@ def main():
     # picked by its share of the SERIALISED run (profiles/traffic.json, `bench.py --serialized`), whose figures are
     # reported beside the live ones.
     # units: rays traced per launch (k_trace, k_primary) / path vertices shaded (k_shade, k_direct)
+    # continuation rays: Scene::intersect calls of the reference = castRay invocations + n_dir per shaded vertex + one look-ahead per
+    # continuing vertex (mcpt_stats.ref_scene_rays), so the look-aheads -- the rays k_trace_closest traces -- follow from the counters;
+    # the primary rays actually traced are the rest of closest_rays (pixels that can only see the background are never traced)
+    n_cont = agg["ref_scene_rays"] - agg["vertices"] - args.n_dir * agg["shaded"]
     kern = {"k_trace<shadow>": (agg["ms_trace_shadow"], agg["n_trace_shadow"], agg["shadow_rays"]),
-            "k_trace<closest>": (agg["ms_trace_closest"], agg["n_trace_closest"], agg["closest_rays"] - agg["samples"]),
-            "k_primary": (agg["ms_generate"], agg["n_generate"], agg["samples"]),
+            "k_trace<closest>": (agg["ms_trace_closest"], agg["n_trace_closest"], n_cont),
+            "k_primary": (agg["ms_generate"], agg["n_generate"], agg["closest_rays"] - n_cont),
             "k_direct": (agg["ms_direct"], agg["n_direct"], agg["direct_vertices"]),
             "k_shade": (agg["ms_shade"], agg["n_shade"], agg["shaded"])}
     prof = load_traffic() or {}
