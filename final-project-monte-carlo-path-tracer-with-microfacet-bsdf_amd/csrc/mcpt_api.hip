@@ -111,12 +111,13 @@ struct SharedBufs {
     DevBuf<uint32_t> pixel_list, key_pixel, key_sample;
     DevBuf<uint32_t> culled_list, cull_count;  // pixel_list partitioned: [may hit | background only] (csrc/mcpt_cull.hip)
     DevBuf<uint8_t> cull_flags, cull_temp;
+    DevBuf<int4> cand_tmp, cand_list;  // per pixel: the few primitives its rays can hit (aligned with culled_list)
     DevBuf<int32_t> key_channel;
     int pix_key[5] = {0, 0, 0, 0, 0};  // (W, H, tile, rank, nranks) of the pixel list currently in HBM
     uint32_t n_pix = 0;
     void release() {
         result.release(); pixel_list.release(); key_pixel.release(); key_sample.release(); key_channel.release();
-        culled_list.release(); cull_count.release(); cull_flags.release(); cull_temp.release();
+        culled_list.release(); cull_count.release(); cull_flags.release(); cull_temp.release(); cand_tmp.release(); cand_list.release();
     }
 };
 
@@ -661,19 +662,23 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     // without a ray; the wavefront loop below runs over the others.  csrc/mcpt_cull.hip has the conservative bound.
     uint32_t n_pix = n_pix_owned;
     const uint32_t *pixel_list = sh.pixel_list.p;
+    const int4 *pixel_cand = nullptr;
     if (sc->knobs.sky_cull && sc->view.env_w <= 0 && n_pix_owned > 0) {
         const size_t tb = cull_temp_bytes(n_pix_owned);
         HIP_TRY(sh.culled_list.alloc(n_pix_owned));
         HIP_TRY(sh.cull_flags.alloc(n_pix_owned));
         HIP_TRY(sh.cull_temp.alloc(tb));
         HIP_TRY(sh.cull_count.alloc(1));
-        uint32_t n_trace = n_pix_owned;
-        HIP_TRY(cull_sky_pixels(sc->view, cc, sh.pixel_list.p, n_pix_owned, sh.culled_list.p, sh.cull_flags.p, sh.cull_temp.p, tb, sh.cull_count.p,
-                                &n_trace, st));
-        if (n_trace < n_pix_owned) {
+        HIP_TRY(sh.cand_tmp.alloc(n_pix_owned));
+        HIP_TRY(sh.cand_list.alloc(n_pix_owned));
+        uint32_t n_trace = n_pix_owned + 1;  // (left untouched when the camera is outside what the bound covers)
+        HIP_TRY(cull_sky_pixels(sc->view, cc, sh.pixel_list.p, n_pix_owned, sh.culled_list.p, sh.cull_flags.p, sh.cand_tmp.p, sh.cand_list.p, sh.cull_temp.p,
+                                tb, sh.cull_count.p, &n_trace, st));
+        if (n_trace <= n_pix_owned) {  // classified: the traced pixels come first, in their original order, with their candidate lists
             launch_sky_fill(sh.culled_list.p + n_trace, n_pix_owned - n_trace, sc->view.background, p.spp, spp_total, fb_dev, st);
             n_pix = n_trace;
             pixel_list = sh.culled_list.p;
+            pixel_cand = sh.cand_list.p;
         }
     }
 
@@ -732,6 +737,7 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     C.seed = p.seed;
     C.mode = 0;
     C.pixel_list = pixel_list;
+    C.pixel_cand = pixel_cand;
     C.max_depth = max_depth;
     C.result[0] = sh.result.p;
     C.result[1] = two_halves ? sh.result.p + half_floats : sh.result.p;

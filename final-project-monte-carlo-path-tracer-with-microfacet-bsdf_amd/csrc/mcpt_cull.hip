@@ -57,7 +57,11 @@ __device__ __forceinline__ bool beam_box(const float o[3], const float d[3], con
     return smax * 1.0001f + 1e-6f >= smin;  // (the slack errs towards "enters")
 }
 
-__global__ __launch_bounds__(kB) void k_classify(DevScene S, CullConst C, const uint32_t *__restrict__ pixels, uint32_t n, uint8_t *__restrict__ may_hit) {
+// Besides the sky / may-hit flag, the walk records WHICH leaves the widened central ray reaches when they are few (at most four
+// primitives): every primitive a sample ray of the pixel can hit is among them, so k_primary tests just those primitives instead of
+// walking the tree (a pixel that sees only the floor: two triangles).  cand.x == kCandTraverse: too many (or an instance): traverse.
+__global__ __launch_bounds__(kB) void k_classify(DevScene S, CullConst C, const uint32_t *__restrict__ pixels, uint32_t n, uint8_t *__restrict__ may_hit,
+                                                  int4 *__restrict__ cand) {
     __shared__ int32_t stk[kMaxBvhHeight + 2][kB];
     const uint32_t g = blockIdx.x * kB + threadIdx.x;
     if (g >= n) return;
@@ -71,13 +75,23 @@ __global__ __launch_bounds__(kB) void k_classify(DevScene S, CullConst C, const 
     for (int a = 0; a < 3; ++a) d[a] = C.orient[3 * a] * fp[0] + C.orient[3 * a + 1] * fp[1] + C.orient[3 * a + 2] * fp[2];
     const float *o = C.eye;
     bool hit = false;
+    int32_t c[4] = {kCandNone, kCandNone, kCandNone, kCandNone};
+    int n_cand = 0;
     if (beam_box(o, d, S.root_min, S.root_max, C.rho)) {
         int32_t cur = S.root;
         int sp = 0;
         while (true) {
-            if (cur < 0) {  // any leaf (a primitive or an instance): a sample ray might hit it
+            if (cur < 0) {  // a leaf (a primitive or an instance): a sample ray might hit it
                 hit = true;
-                break;
+                const bool prim_leaf = (uint32_t)(~cur) < (uint32_t)S.n_leaf_prims || S.inst == nullptr;
+                if (!prim_leaf || n_cand == 4) {  // an instance, or a fifth primitive: this pixel's rays walk the tree
+                    n_cand = 5;
+                    break;
+                }
+                c[n_cand++] = cur;
+                if (sp == 0) break;
+                cur = stk[--sp][tid];
+                continue;
             }
             const Node N = S.nodes[cur];
             const bool hl = beam_box(o, d, N.lmin, N.lmax, C.rho), hr = beam_box(o, d, N.rmin, N.rmax, C.rho);
@@ -95,6 +109,7 @@ __global__ __launch_bounds__(kB) void k_classify(DevScene S, CullConst C, const 
         }
     }
     may_hit[g] = hit ? 1 : 0;
+    cand[g] = n_cand > 4 ? make_int4(kCandTraverse, 0, 0, 0) : make_int4(c[0], c[1], c[2], c[3]);
 }
 
 // framebuffer[m] += background / spp, spp times, in order (Renderer.cpp:80 with every sample equal to the miss value)
@@ -112,8 +127,7 @@ __global__ __launch_bounds__(kB) void k_sky_fill(const uint32_t *__restrict__ sk
 }  // namespace
 
 hipError_t cull_sky_pixels(const DevScene &S, const CameraConst &cam, const uint32_t *d_pixels, uint32_t n, uint32_t *d_out, uint8_t *d_flags,
-                           void *d_temp, size_t temp_bytes, uint32_t *d_count, uint32_t *n_trace, hipStream_t st) {
-    *n_trace = n;
+                           int4 *d_cand_tmp, int4 *d_cand_out, void *d_temp, size_t temp_bytes, uint32_t *d_count, uint32_t *n_trace, hipStream_t st) {
     CullConst C;
     for (int a = 0; a < 3; ++a) C.eye[a] = cam.eye[a];
     for (int a = 0; a < 9; ++a) C.orient[a] = cam.orient[a];
@@ -140,8 +154,10 @@ hipError_t cull_sky_pixels(const DevScene &S, const CameraConst &cam, const uint
     const double rho = std::max((double)C.lens, std::fabs(1.0 - s_far) * C.lens + s_far * h);
     C.rho = (float)(1.05 * rho + 1e-4 * (half + std::sqrt(eye_n) + std::sqrt(eye_c)) + 1e-3);
     if (!std::isfinite(C.rho)) return hipSuccess;
-    hipLaunchKernelGGL(k_classify, dim3(nblocks(n)), dim3(kB), 0, st, S, C, d_pixels, n, d_flags);
+    hipLaunchKernelGGL(k_classify, dim3(nblocks(n)), dim3(kB), 0, st, S, C, d_pixels, n, d_flags, d_cand_tmp);
     hipError_t e = hipcub::DevicePartition::Flagged(d_temp, temp_bytes, d_pixels, d_flags, d_out, d_count, (int)n, st);
+    if (e != hipSuccess) return e;
+    e = hipcub::DevicePartition::Flagged(d_temp, temp_bytes, d_cand_tmp, d_flags, d_cand_out, d_count, (int)n, st);  // the same order
     if (e != hipSuccess) return e;
     uint32_t cnt = 0;
     e = hipMemcpyAsync(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost, st);
@@ -153,9 +169,10 @@ hipError_t cull_sky_pixels(const DevScene &S, const CameraConst &cam, const uint
 }
 
 size_t cull_temp_bytes(uint32_t n) {
-    size_t bytes = 0;
-    (void)hipcub::DevicePartition::Flagged(nullptr, bytes, (const uint32_t *)nullptr, (const uint8_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
-    return bytes;
+    size_t a = 0, b = 0;
+    (void)hipcub::DevicePartition::Flagged(nullptr, a, (const uint32_t *)nullptr, (const uint8_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
+    (void)hipcub::DevicePartition::Flagged(nullptr, b, (const int4 *)nullptr, (const uint8_t *)nullptr, (int4 *)nullptr, (uint32_t *)nullptr, (int)n);
+    return a > b ? a : b;
 }
 
 void launch_sky_fill(const uint32_t *sky_pixels, uint32_t n_sky, const float background[3], int32_t spp, float spp_total, float *fb, hipStream_t st) {

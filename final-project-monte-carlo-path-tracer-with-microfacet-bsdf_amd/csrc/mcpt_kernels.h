@@ -65,12 +65,17 @@ struct Scratch {
     float4 *shq_d;  // {direction.xyz, distance to the light sample}
 };
 
+// Per-pixel candidate primitives for the primary rays (csrc/mcpt_cull.hip)
+constexpr int32_t kCandNone = 0x7fffffff;      // unused entry
+constexpr int32_t kCandTraverse = 0x7ffffffe;  // in .x: no short list for this pixel, walk the tree
+
 struct RenderConst {
     float rr_rate, inv_rr;
     int32_t n_dir, enable_shadow;
     uint32_t seed;
     int32_t mode;  // 0: pid -> (pixel list, sample); 1: explicit per-path keys (mcpt_cast_rays)
     const uint32_t *pixel_list;
+    const int4 *pixel_cand;  // aligned with pixel_list, or nullptr (every primary ray walks the tree)
     int32_t s_pass[2], sample_offset[2];  // per pass parity: two passes can be in flight
     int32_t s_pass_shift[2];              // log2(s_pass) when it is a power of two (the usual 256: a shift instead of a division), else -1
     const uint32_t *key_pixel, *key_sample;

@@ -633,7 +633,24 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
         const uint32_t k = (uint32_t)(q ? C.sample_offset[1] : C.sample_offset[0]) + ks;
         camera_ray(cam, C.seed, m, k, pos, dir);
         const Ray r = make_ray(pos, dir);
-        tr = traverse<false, STK>(S, r, 0.f, stk, tid);
+        const int4 cd = C.pixel_cand ? C.pixel_cand[pl] : make_int4(kCandTraverse, 0, 0, 0);
+        if (cd.x == kCandTraverse) {
+            tr = traverse<false, STK>(S, r, 0.f, stk, tid);
+        } else {
+            // every primitive a ray of this pixel can hit is in the list (csrc/mcpt_cull.hip): test those, with the traversal's tie rule
+            const int32_t cs[4] = {cd.x, cd.y, cd.z, cd.w};
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                if (cs[q4] == kCandNone) continue;
+                const int32_t prim = ~cs[q4];
+                double t = 0;
+                if (prim_hit(S, prim, r, t) && (t < tr.t || (t == tr.t && prim > tr.prim))) {
+                    tr.t = t;
+                    tr.prim = prim;
+                    tr.mat_bits = prim < S.n_tri ? S.tri_geom[prim].mat_bits : S.spheres[prim - S.n_tri].mat_bits;
+                }
+            }
+        }
         if (tr.prim < 0) {
             const f3 env = sample_env(S, dir);
             result[(size_t)s * 3 + 0] = env.x;
