@@ -137,6 +137,13 @@ hipError_t cull_sky_pixels(const DevScene &S, const CameraConst &cam, const uint
     C.lens = cam.use_dof ? fabsf(cam.aperture_radius) : 0.0f;
     C.width = cam.width;
     C.height = cam.height;
+    // the bound takes |O v| = |v| (Camera::lookAt builds an orthonormal matrix, Camera.hpp:17-24): any other matrix, no culling
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            double dotp = 0;
+            for (int k = 0; k < 3; ++k) dotp += (double)C.orient[3 * k + a] * C.orient[3 * k + b];
+            if (std::fabs(dotp - (a == b ? 1.0 : 0.0)) > 1e-4) return hipSuccess;
+        }
     // h, s_far, rho (see the header comment), all on the host in double
     const double h = std::fabs((double)C.focal) * std::sqrt(std::pow((double)C.aspect * C.scale / C.width, 2) + std::pow((double)C.scale / C.height, 2));
     double centre[3], half = 0, eye_c = 0, eye_n = 0;

@@ -85,6 +85,13 @@ def test_culling_with_partitions_progressive_calls_and_an_all_sky_frame(pkg, hip
     for _ in range(7):
         acc += np.asarray(sd.background, np.float32) / np.float32(7)
     assert (fb == acc).all() and st.closest_rays == 0 and st.samples == 64 * 48 * 7 and st.vertices == 3 * st.samples
+    # a camera matrix that is not orthonormal is outside what the bound covers: nothing is culled, the frame is still right
+    odd = np.array(sd.camera, copy=True)
+    odd["orientation"] = (np.asarray(sd.camera["orientation"]).reshape(3, 3) * np.float32(1.3)).reshape(-1)
+    monkeypatch.delenv("MCPT_SKY_CULL", raising=False)
+    a, sa = hip.HipScene(sd).render(camera=odd, spp=2, seed=1)
+    b, sb = _render(hip, sd, monkeypatch, False, camera=odd, spp=2, seed=1)
+    assert np.array_equal(a, b, equal_nan=True) and sa.closest_rays == sb.closest_rays
     # with an environment map the miss value depends on the direction: nothing is culled
     sd2 = pkg.scenes.chess_scene(width=96, height=54, spp=2)
     sd2.env_pixels = np.random.default_rng(0).random((8, 16, 3)).astype(np.float32)
