@@ -146,6 +146,21 @@ def test_render_is_bit_identical_with_the_reference_tree(pkg, oracle, hip, name,
     assert st_gpu.vertices == st_ref.vertices and st_gpu.ref_scene_rays == st_ref.scene_rays
 
 
+@pytest.mark.parametrize("name", ["cornell_demo_48x48_spp4", "chess_96x54_spp2"])
+def test_gpu_reproduces_the_committed_golden_frames(pkg, hip, name, tree_env):
+    """tests/golden/oracle_*.npy (frames of the CPU oracle, committed): the GPU frame is the same array, bit for bit, with the reference's
+    tree -- a target that does not depend on building or running the oracle on the GPU box."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_%s.npy" % name))
+    sd, spp = (pkg.scenes.cornell_demo(48, 48, 4), 4) if name.startswith("cornell") else (pkg.scenes.chess_scene(width=96, height=54, spp=2), 2)
+    tree_env("reference", "0")
+    fb, _ = hip.HipScene(sd).render(spp=spp, seed=1)
+    assert _same_bits(fb, g).all()
+    tree_env("sah", None)
+    fb, _ = hip.HipScene(sd).render(spp=spp, seed=1)
+    assert (~_same_bits(fb, g)).sum() <= 3
+
+
 def test_render_psnr_cornell_demo(pkg, oracle, hip):
     sd = pkg.scenes.cornell_demo(96, 96, 16)
     psnr, st_ref, st_gpu, fb_ref, fb_gpu = _psnr_case(pkg, oracle, hip, sd, 16)
