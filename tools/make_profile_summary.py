@@ -67,7 +67,7 @@ def main(d, tag):
     json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     for src, dst in (("kernel_stats_no_overlap_64spp.csv", "%s_kernel_stats_no_overlap_64spp_step.csv"), ("kernel_stats_overlap.csv", "%s_kernel_stats_overlap.csv"),
                      ("pmc_summary_no_overlap_64spp_step.json", "%s_pmc_summary_no_overlap_64spp_step.json"), ("trace_busy_overlap.txt", "%s_timeline_overlap.txt"),
-                     ("bench.json", "%s_bench.json"), ("bench_serialized_64spp.json", "%s_bench_serialized_64spp.json"),
+                     ("bench.json", "%s_bench.json"), ("bench_profiled_overlap.json", "%s_bench_profiled_overlap.json"), ("bench_serialized_64spp.json", "%s_bench_serialized_64spp.json"),
                      ("bench_config2_cornell_rc_784_spp256.json", "%s_bench_config2_cornell_rc_784_spp256.json"),
                      ("bench_config3_chess_spp512.json", "%s_bench_config3_chess_spp512.json"),
                      ("bench_config4_chess_spp2048_ndir32.json", "%s_bench_config4_chess_spp2048_ndir32.json"),

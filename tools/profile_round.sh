@@ -8,7 +8,10 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err || exit 1
 echo "bench done"; tail -c 400 $O/bench.json; echo
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline --no-psnr > $O/kt.log 2>&1 || exit 1
+# (--warmup 0: every launch of the profiled process lies in bench.py's timed region, so the per-kernel averages of its JSON line and of
+# the rocprofv3 statistics are averages over the same launches)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --warmup 0 --no-cpu-baseline --no-psnr > $O/kt.log 2>&1 || exit 1
+grep "^{" $O/kt.log | tail -1 > $O/bench_profiled_overlap.json
 f=$(find $O/kt -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats_overlap.csv
 t=$(find $O/kt -name "*kernel_trace.csv" | head -1); python3 $R/tools/trace_busy.py $t 0.3 > $O/trace_busy_overlap.txt
 rm -rf $O/kt; echo "kernel trace done"
