@@ -11,6 +11,7 @@
 // test it); std::stable_sort replaces the reference's unstable std::sort, whose tie order is unspecified.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -186,6 +187,190 @@ BNode *sah_build(Arena &A, std::vector<BObj *> &objs, size_t begin, size_t end) 
     node->bounds = box_union(node->left->bounds, node->right->bounds);
     node->area = node->left->area + node->right->area;
     return node;
+}
+
+// Reinsertion pass over a finished SAH tree (the idea of Bittner, Hapala, Havran 2013 and Meister & Bittner 2018, sequential):
+// a subtree n is cut out (its sibling takes the parent's place) and hung back in where the sum of the inner nodes' surface areas
+// grows least; moves that do not lower that sum are not made.  The search walks up from n's parent and explores, at every level,
+// the subtree beside the path by branch and bound: `budget` is the area saved on the path below, minus the growth of the boxes
+// passed on the way down.  Only topology changes: boxes stay exact unions, every primitive stays one leaf, so hits are the same
+// (ties: the larger primitive id, as with any tree).  `max_height` keeps the traversal stack class of the tree (levels incl. leaf).
+struct Reinserter {
+    struct N {
+        Box b;
+        float a;  // half surface area of b
+        int parent, left, right;
+        int h;    // levels below (leaf: 0)
+        BObj *obj;
+    };
+    std::vector<N> t;
+    int root = -1;
+
+    int import(const BNode *n, int parent) {
+        const int idx = (int)t.size();
+        t.emplace_back();
+        t[idx].b = n->bounds;
+        t[idx].a = half_area(n->bounds);
+        t[idx].parent = parent;
+        t[idx].obj = n->obj;
+        t[idx].left = t[idx].right = -1;
+        t[idx].h = 0;
+        if (!n->obj) {
+            const int l = import(n->left, idx), r = import(n->right, idx);
+            t[idx].left = l;
+            t[idx].right = r;
+            t[idx].h = 1 + std::max(t[l].h, t[r].h);
+        }
+        return idx;
+    }
+    BNode *emit(Arena &A, int i) const {
+        BNode *n = A.make();
+        n->bounds = t[i].b;
+        if (t[i].obj) {
+            n->obj = t[i].obj;
+            n->area = t[i].obj->area;
+            return n;
+        }
+        n->left = emit(A, t[i].left);
+        n->right = emit(A, t[i].right);
+        n->area = n->left->area + n->right->area;
+        return n;
+    }
+    double cost() const {  // sum of the inner nodes' areas over the root's: expected node visits of a random ray through the root box
+        double c = 0;
+        for (const N &n : t)
+            if (!n.obj && n.parent != -2) c += n.a;
+        return c / t[root].a;
+    }
+    int sibling(int i) const {
+        const N &p = t[t[i].parent];
+        return p.left == i ? p.right : p.left;
+    }
+    int depth(int i) const {  // root: 1
+        int d = 1;
+        while (t[i].parent >= 0) {
+            i = t[i].parent;
+            ++d;
+        }
+        return d;
+    }
+    void refit_up(int i) {
+        for (; i >= 0; i = t[i].parent) {
+            N &n = t[i];
+            n.b = box_union(t[n.left].b, t[n.right].b);
+            n.a = half_area(n.b);
+            n.h = 1 + std::max(t[n.left].h, t[n.right].h);
+        }
+    }
+    struct Item {
+        float budget;
+        int node, depth;
+    };
+    std::vector<Item> stk;
+
+    // best position for subtree n (not the root, parent not the root); returns the gain (0: leave it) and the target in `to`
+    float find(int n, int max_height, int &to) {
+        const int p = t[n].parent;
+        const Box nb_n = t[n].b;
+        const float an = t[n].a;
+        const int hn = t[n].h;
+        float best = 0.f;
+        to = -1;
+        float budget = t[p].a;           // p disappears
+        Box path_box = t[sibling(n)].b;  // what p's slot holds afterwards
+        int pivot = p, sib = sibling(n), level = 0;
+        int d_pivot = depth(p);
+        while (true) {
+            // after the cut the sibling's subtree sits one level higher (level 0); the subtrees beside the path keep their depth
+            stk.clear();
+            stk.push_back({budget, sib, level == 0 ? d_pivot : d_pivot + 1});
+            while (!stk.empty()) {
+                const Item it = stk.back();
+                stk.pop_back();
+                if (it.budget - an <= best) continue;  // the new parent's box is at least n's
+                const N &x = t[it.node];
+                const float merged = half_area(box_union(x.b, nb_n));
+                const float gain = it.budget - merged;
+                // new parent at it.depth, x and n one below: deepest leaf level it.depth + 1 + max(h)
+                if (gain > best && it.depth + 1 + std::max(x.h, hn) <= max_height && !(level == 0 && it.node == sib)) {
+                    best = gain;
+                    to = it.node;
+                }
+                if (!x.obj) {
+                    const float below = gain + x.a;  // budget - (merged - area(x))
+                    stk.push_back({below, x.left, it.depth + 1});
+                    stk.push_back({below, x.right, it.depth + 1});
+                }
+            }
+            if (t[pivot].parent < 0) break;
+            if (level > 0) {
+                path_box = box_union(path_box, t[sib].b);
+                budget += t[pivot].a - half_area(path_box);
+            }
+            sib = sibling(pivot);
+            pivot = t[pivot].parent;
+            --d_pivot;
+            ++level;
+        }
+        return best;
+    }
+    void move(int n, int to) {
+        const int p = t[n].parent, s = sibling(n), g = t[p].parent;
+        // cut: s takes p's place under g
+        (t[g].left == p ? t[g].left : t[g].right) = s;
+        t[s].parent = g;
+        refit_up(g);
+        // p becomes the new parent of (to, n), in to's place
+        const int q = t[to].parent;
+        (t[q].left == to ? t[q].left : t[q].right) = p;
+        t[p].parent = q;
+        t[p].left = to;
+        t[p].right = n;
+        t[to].parent = p;
+        t[n].parent = p;
+        refit_up(p);
+    }
+    // one pass over the nodes, largest boxes first; returns the number of moves
+    int pass(int max_height, float min_gain) {
+        std::vector<int> order;
+        order.reserve(t.size());
+        for (int i = 0; i < (int)t.size(); ++i)
+            if (i != root && t[i].parent != root) order.push_back(i);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return t[a].a > t[b].a || (t[a].a == t[b].a && a < b); });
+        int moves = 0;
+        for (int n : order) {
+            if (t[n].parent == root || n == root) continue;  // (earlier moves may have lifted it)
+            int to;
+            const float g = find(n, max_height, to);
+            if (to >= 0 && g > min_gain) {
+                move(n, to);
+                ++moves;
+            }
+        }
+        return moves;
+    }
+};
+
+// MCPT_BVH_REINSERT=<passes>; off by default.  Measured on the chess scene: 4 passes move 7300 subtrees in 0.65 s
+// of host time; shadow rays visit 5 % fewer nodes, closest-hit rays 0.3 %, the frame renders 0.7 % faster -- worth it only for
+// renders much longer than the build.  Without the height limit the area sum falls by 19 % but node visits by 1 %, and the 24-level
+// tree needs the next stack class (one resident workgroup per CU less): slower.
+constexpr int kReinsertPasses = 0;
+BNode *reinsertion_optimise(Arena &A, BNode *root, int passes, bool verbose) {
+    if (passes <= 0 || root->obj) return root;
+    Reinserter R;
+    R.root = R.import(root, -1);
+    if (R.t.size() < 8) return root;
+    // keep the stack class: the kernels are instantiated for 16, 20, 24, 32, ... levels
+    const int h0 = R.t[R.root].h + 1;
+    const int max_height = h0 <= 16 ? 16 : (h0 <= 20 ? 20 : (h0 <= 24 ? 24 : (h0 <= 32 ? 32 : h0)));
+    const double c0 = R.cost();
+    for (int k = 0; k < passes; ++k) {
+        const int moves = R.pass(max_height, 1e-7f * R.t[R.root].a);
+        if (verbose) std::fprintf(stderr, "[mcpt bvh] reinsertion pass %d: %d moves, cost %.3f -> %.3f, height %d\n", k + 1, moves, c0, R.cost(), R.t[R.root].h + 1);
+        if (moves == 0) break;
+    }
+    return R.emit(A, R.root);
 }
 
 inline void store3(float *d, V3 v) {
@@ -575,7 +760,11 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, 
             else
                 for (int k = 0; k < d.objects[oi].n_tri; ++k) prims.push_back(&tri_objs[d.objects[oi].first_tri + k]);
         }
-        root = sah_build(arena, prims, 0, prims.size());
+        BNode *r = sah_build(arena, prims, 0, prims.size());
+        const char *e = std::getenv("MCPT_BVH_REINSERT");
+        const int passes = e ? std::atoi(e) : kReinsertPasses;
+        if (inst_leaf_objs.empty()) r = reinsertion_optimise(arena, r, passes, std::getenv("MCPT_BVH_VERBOSE") != nullptr);
+        root = r;
     }
 
     hs.nodes.reserve((size_t)d.n_triangles + d.n_objects + 8);

@@ -86,6 +86,26 @@ def test_tree_invariants(pkg, hip, monkeypatch, scene, topology):
         assert info["quantised"] == 1 and h <= 24  # the chess tree fits the 20/24-entry traversal stacks
 
 
+def test_reinsertion_pass_keeps_the_tree_valid(pkg, hip, monkeypatch):
+    """MCPT_BVH_REINSERT: subtrees are re-hung where the area sum grows least; every primitive is still exactly one leaf, boxes are
+    exact unions, and the tree stays within the stack class it had (check_tree), with a smaller sum of inner-node areas."""
+    def area_sum(boxes, children):
+        b = boxes.reshape(-1, 2, 6).astype(np.float64)
+        d = b[:, :, 3:6] - b[:, :, 0:3]
+        a = d[:, :, 0] * d[:, :, 1] + d[:, :, 1] * d[:, :, 2] + d[:, :, 2] * d[:, :, 0]
+        return float(a[children >= 0].sum())
+    sd = pkg.scenes.chess_scene(width=64, height=64, spp=1)
+    info0, boxes0, children0, _ = hip.bvh_dump(sd)
+    monkeypatch.setenv("MCPT_BVH_REINSERT", "3")
+    info, boxes, children, qboxes = hip.bvh_dump(sd)
+    h = check_tree(sd, info, boxes, children, qboxes)
+    assert info["n_nodes"] == info0["n_nodes"] and info["stack_entries"] == info0["stack_entries"] and h <= info["stack_entries"]
+    assert not np.array_equal(children, children0) and area_sum(boxes, children) < 0.99 * area_sum(boxes0, children0)
+    for scene in ("cornell_demo", "cornell_rc"):
+        s2 = getattr(pkg.scenes, scene)(32, 32, 1)
+        check_tree(s2, *hip.bvh_dump(s2))
+
+
 def test_quantisation_can_be_switched_off(pkg, hip, monkeypatch):
     monkeypatch.setenv("MCPT_QUANT_NODES", "0")
     info, boxes, children, qboxes = hip.bvh_dump(pkg.scenes.cornell_demo(32, 32, 1))

@@ -146,6 +146,17 @@ def test_render_is_bit_identical_with_the_reference_tree(pkg, oracle, hip, name,
     assert st_gpu.vertices == st_ref.vertices and st_gpu.ref_scene_rays == st_ref.scene_rays
 
 
+@pytest.mark.gpu
+def test_render_with_the_reinsertion_pass_matches_the_oracle(pkg, oracle, hip, monkeypatch):
+    """MCPT_BVH_REINSERT (opt-in tree optimisation): another topology, the same frame and the same counters as the oracle."""
+    monkeypatch.setenv("MCPT_BVH_REINSERT", "4")
+    sd = pkg.scenes.chess_scene(width=240, height=135, spp=8)
+    psnr, st_ref, st_gpu, fb_ref, fb_gpu = _psnr_case(pkg, oracle, hip, sd, 8, spp_per_pass=3)
+    bad = ~_same_bits(fb_ref, fb_gpu)
+    assert bad.sum() <= 3, "%d of %d framebuffer values differ" % (bad.sum(), bad.size)  # (box-grazing rays: DESIGN.md section 3)
+    assert abs(int(st_gpu.vertices) - int(st_ref.vertices)) <= 4
+
+
 @pytest.mark.parametrize("name", ["cornell_demo_48x48_spp4", "chess_96x54_spp2"])
 def test_gpu_reproduces_the_committed_golden_frames(pkg, hip, name, tree_env):
     """tests/golden/oracle_*.npy (frames of the CPU oracle, committed): the GPU frame is the same array, bit for bit, with the reference's
