@@ -962,7 +962,7 @@ int mcpt_scene_create_ex(const mcpt_scene_desc *desc, int device, const mcpt_bui
     } else {
         sc->n_inner = hs.root < 0 ? 0 : (int32_t)hs.nodes.size();
     }
-    if (traversal_stack_entries(hs.height) < hs.height) {  // whatever built the tree: a push beyond the LDS stack would be dropped
+    if (traversal_stack_entries(hs.height) < hs.height - 1) {  // whatever built the tree: a push beyond the stack (one entry per inner ancestor) would be dropped
         mcpt_scene_destroy(sc);
         return fail(MCPT_ERR_LIMIT, "the BVH is deeper than the traversal stack (kMaxBvhHeight)");
     }

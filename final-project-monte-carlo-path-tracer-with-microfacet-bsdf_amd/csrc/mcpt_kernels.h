@@ -98,10 +98,14 @@ struct CameraConst {
     float orient[9];
 };
 
-// LDS traversal-stack entries per lane the traversal kernels are instantiated with for a tree of this height (a ray pushes at most
-// one child reference per inner ancestor, i.e. height - 1).  0: the tree is too deep for any instantiation.
+// Traversal-stack entries per lane the traversal kernels provide for a tree of this height (a ray holds at most one child reference
+// per inner ancestor, i.e. height - 1).  0: the tree is too deep for any instantiation.
+#ifndef MCPT_STK_B
+#define MCPT_STK_B 19
+#endif
+constexpr int kStkB = MCPT_STK_B;  // entries for trees of height 17..20 (19 is exact for height 20, and 19 KB + the allocation block of k_primary still fit 8 workgroups into the 160 KB of a CU; 20 fit 7: +1 % on the chess frame)
 inline int traversal_stack_entries(int height) {
-    return height <= 16 ? 16 : (height <= 20 ? 20 : (height <= 24 ? 24 : (height <= 32 ? 32 : (height <= kMaxBvhHeight ? kMaxBvhHeight : 0))));
+    return height <= 17 ? 16 : (height <= 20 ? kStkB : (height <= kMaxBvhHeight ? kMaxBvhHeight : 0));  // (deeper than 20: 16 in LDS, and the scratch stack of kMaxBvhHeight entries for rays that need more)
 }
 
 void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, uint32_t start, uint32_t mask, hipStream_t s);

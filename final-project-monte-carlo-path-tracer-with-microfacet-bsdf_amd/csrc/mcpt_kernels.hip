@@ -133,10 +133,45 @@ struct TraceState {
     int32_t best_prim;
     uint32_t best_mat;
     bool occluded, found;
+    bool dropped;  // a stack entry was lost (retry flavour): the result is void
 #ifdef MCPT_TRAVERSAL_STATS
-    unsigned nv, nt, iters;
+    unsigned nv, nt, iters, maxsp;
 #endif
 };
+
+// The per-lane traversal stack: STK entries in LDS (column `tid` of stk[][kBlock]).  A ray holds at most one entry per inner ancestor
+// (tree height - 1), but the deepest stack any ray of the chess frames reaches is 11-12 entries (SAH trees of height 20-24) or 14-15
+// (LBVH, height 27-36; tools/traversal_stats_env.py), while every LDS entry costs 1 KB per workgroup and, beyond 19, resident
+// workgroups (20-22 entries: 7 per CU, 23-26: 6, 32: 5, 48: 3).  Three flavours:
+//   plain   trees of up to 24 levels: STK >= height - 1 LDS entries, a push can never fail.
+//   retry   deeper trees (RETRY): 16 LDS entries; a push onto a full stack drops the entry and marks the ray (`dropped`).  The walk goes on
+//           (it only visits less) and its result is thrown away: a marked ray is traced again, from the start, by the
+//   scratch flavour (STK = 0, SCR): the whole stack is a per-lane array of kMaxBvhHeight entries in scratch memory -- slow and exact.
+// Results never depend on the stack size: the checking build (-DMCPT_FORCE_RETRY -DMCPT_STK_RETRY=4) retraces most rays of every
+// scene and renders the same frames (tests/test_gpu_checks.py).  Measured, chess frame with the GPU-built tree (27 levels): 32 LDS
+// entries 3700 Msamples/s, retry flavour 4000 (8 workgroups per CU instead of 5); the second copy of the loop costs registers and
+// instruction cache, though (the same kernels with 16 entries and no retry code: 4280), which is why 21-24-level trees keep their
+// 24 LDS entries (the 296 k-triangle scene: 4090 with 24 entries, 3800 with the retry flavour, 4140 with 16 entries and no retry
+// code).  An overflow array behind the LDS entries inside the hot loop (one compare per pop) measured 4000 on that scene too.
+#ifndef MCPT_STK_RETRY
+#define MCPT_STK_RETRY 16
+#endif
+constexpr int kStkRetry = MCPT_STK_RETRY;  // LDS entries of the retry flavour (the checking build: 4, and every tree uses it)
+template <int STK, bool SCR>
+MCPT_DI void stk_push(int32_t (*stk)[kBlock], int32_t *scr, int tid, int &sp, int32_t v, bool &dropped) {
+    if (SCR) {
+        if (sp < kMaxBvhHeight) scr[sp++] = v;  // (never full: mcpt_scene_create refuses trees deeper than kMaxBvhHeight)
+    } else if (sp < STK) {
+        stk[sp++][tid] = v;
+    } else {
+        dropped = true;  // plain flavour: never (STK >= height - 1); retry flavour: the ray is traced again
+    }
+}
+template <int STK, bool SCR>
+MCPT_DI int32_t stk_pop(int32_t (*stk)[kBlock], const int32_t *scr, int tid, int &sp) {  // sp > 0
+    --sp;
+    return SCR ? scr[sp] : stk[sp][tid];
+}
 
 // Speculative while-while loop (Aila & Laine 2009, "Understanding the efficiency of ray traversal on GPUs").  A plain
 // `if (inner) node-step else leaf-test` loop makes a wave pay for BOTH bodies in nearly every iteration (with 64 lanes, some lane
@@ -157,8 +192,8 @@ struct TraceState {
 constexpr int32_t kNoWork = (int32_t)0x80000000;   // neither an inner node (>= 0) nor a leaf (~index, index < 2^31 - 2)
 constexpr int32_t kInstExit = (int32_t)0x80000001; // stack marker: the subtree of the current instance is exhausted
 constexpr int kLeafVote = 12;
-template <int MODE, int STK, bool FAST, bool QUANT, bool INST>
-MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, TraceState &st) {
+template <int MODE, int STK, bool SCR, bool FAST, bool QUANT, bool INST>
+MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int32_t *scr, int tid, TraceState &st) {
     QRay qr;
     if (QUANT) qr = make_qray(S, r);
     Ray rb = r;               // the ray of the box tests (origin shifted inside an instance)
@@ -187,14 +222,14 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
                     rb.o = r.o;
                     prim_base = 0;
                     if (QUANT) qr.b = make_qray(S, r).b;
-                    cur = (sp == 0) ? kNoWork : stk[--sp][tid];
+                    cur = (sp == 0) ? kNoWork : stk_pop<STK, SCR>(stk, scr, tid, sp);
                 }
                 if (cur > kInstExit && cur < 0 && (uint32_t)(~cur) >= n_leaf_prims) {  // an instance: enter its prototype's subtree
                     const InstRec I = S.inst[(uint32_t)(~cur) - n_leaf_prims];
                     rb.o = mk3(r.o.x - I.shift[0], r.o.y - I.shift[1], r.o.z - I.shift[2]);
                     prim_base = I.first_tri;
                     if (QUANT) qr.b = make_qray(S, rb).b;
-                    if (sp < STK) stk[sp++][tid] = kInstExit;
+                    stk_push<STK, SCR>(stk, scr, tid, sp, kInstExit, st.dropped);
                     cur = I.root;
                 }
             }
@@ -232,18 +267,24 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
                 if (hl && hr) {
                     const bool swap = tr < tl;
                     const int32_t nearc = swap ? right : left, farc = swap ? left : right;
-                    if (sp < STK) stk[sp++][tid] = farc;  // (never full: the launcher picks STK >= the tree height, asserted at scene creation)
+#ifdef MCPT_TRAVERSAL_STATS
+                    const int sp_before = sp;
+#endif
+                    stk_push<STK, SCR>(stk, scr, tid, sp, farc, st.dropped);
+#ifdef MCPT_TRAVERSAL_STATS
+                    st.maxsp = max(st.maxsp, sp == sp_before ? 1000u : (unsigned)sp);  // (1000: a dropped entry)
+#endif
                     cur = nearc;
                 } else if (hl) {
                     cur = left;
                 } else if (hr) {
                     cur = right;
                 } else {
-                    cur = (sp == 0) ? kNoWork : stk[--sp][tid];
+                    cur = (sp == 0) ? kNoWork : stk_pop<STK, SCR>(stk, scr, tid, sp);
                 }
                 if (cur < 0 && (uint32_t)(~cur) < n_leaf_prims && leaf == kNoWork) {  // first leaf of the round: park it and keep traversing
                     leaf = ~(prim_base + ~cur);  // (a global primitive id from here on)
-                    cur = (sp == 0) ? kNoWork : stk[--sp][tid];
+                    cur = (sp == 0) ? kNoWork : stk_pop<STK, SCR>(stk, scr, tid, sp);
                 }
             }
             // a lane can still make progress on nodes if it holds an inner node (or, INST, an instance / exit marker)
@@ -288,7 +329,7 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
             leaf = kNoWork;
             if (cur < 0 && (uint32_t)(~cur) < n_leaf_prims) {  // a second leaf was waiting: park it for the next round
                 leaf = ~(prim_base + ~cur);
-                cur = (sp == 0) ? kNoWork : stk[--sp][tid];
+                cur = (sp == 0) ? kNoWork : stk_pop<STK, SCR>(stk, scr, tid, sp);
             }
         }
         if (cur == kNoWork && leaf == kNoWork) return;
@@ -307,27 +348,25 @@ MCPT_DI bool prim_hit(const DevScene &S, int32_t prim, const Ray &r, double &t) 
     return h;
 }
 
-// found: shadow queries only -- the window search is already settled (k_direct found the sampled primitive in the window).
-template <bool SHADOW, int STK>
-MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, bool found = false) {
-    TraceState st;
+// One complete query with one stack flavour.  found: shadow queries only -- the window search is already settled (k_direct found the
+// sampled primitive in the window).
+template <bool SHADOW, int STK, bool SCR>
+MCPT_DI void traverse_once(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int32_t *scr, int tid, bool found, TraceState &st) {
     st.best_t = DBL_MAX;
     st.best_prim = -1;
     st.best_mat = 0;
     st.occluded = false;
     st.found = found;
-#ifdef MCPT_TRAVERSAL_STATS
-    st.nv = st.nt = st.iters = 0;
-#endif
-#define TL(MODE, FAST)                                                                           \
-    do {                                                                                         \
-        if (S.inst) {                                                                            \
-            if (S.qnodes) traverse_loop<MODE, STK, FAST, true, true>(S, r, dist, stk, tid, st);  \
-            else traverse_loop<MODE, STK, FAST, false, true>(S, r, dist, stk, tid, st);          \
-        } else {                                                                                 \
-            if (S.qnodes) traverse_loop<MODE, STK, FAST, true, false>(S, r, dist, stk, tid, st); \
-            else traverse_loop<MODE, STK, FAST, false, false>(S, r, dist, stk, tid, st);         \
-        }                                                                                        \
+    st.dropped = false;
+#define TL(MODE, FAST)                                                                                     \
+    do {                                                                                                   \
+        if (S.inst) {                                                                                      \
+            if (S.qnodes) traverse_loop<MODE, STK, SCR, FAST, true, true>(S, r, dist, stk, scr, tid, st);  \
+            else traverse_loop<MODE, STK, SCR, FAST, false, true>(S, r, dist, stk, scr, tid, st);          \
+        } else {                                                                                           \
+            if (S.qnodes) traverse_loop<MODE, STK, SCR, FAST, true, false>(S, r, dist, stk, scr, tid, st); \
+            else traverse_loop<MODE, STK, SCR, FAST, false, false>(S, r, dist, stk, scr, tid, st);         \
+        }                                                                                                  \
     } while (0)
     // Wave-uniform choice of the slab-test flavour: the exact NaN-faithful chain only when some lane of the wave
     // has a non-finite reciprocal (a zero direction component); otherwise the bit-identical max3/min3 form.
@@ -347,6 +386,26 @@ MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_
     } else {
         TL(kClosest, false);
     }
+#undef TL
+}
+
+// The scratch flavour: the ray again, from the start, with the whole stack in a per-lane array (see stk_push).
+template <bool SHADOW>
+MCPT_DI void traverse_again(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, bool found, TraceState &st) {
+    int32_t scr[kMaxBvhHeight];
+    traverse_once<SHADOW, 0, true>(S, r, dist, stk, scr, tid, found, st);
+}
+
+template <bool SHADOW, int STK, bool RETRY>
+MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, bool found = false) {
+    TraceState st;
+#ifdef MCPT_TRAVERSAL_STATS
+    st.nv = st.nt = st.iters = st.maxsp = 0;
+#endif
+    traverse_once<SHADOW, STK, false>(S, r, dist, stk, nullptr, tid, found, st);
+    if (RETRY) {
+        if (st.dropped) traverse_again<SHADOW>(S, r, dist, stk, tid, found, st);
+    }
 #ifdef MCPT_TRAVERSAL_STATS
     if (S.dbg) {  // [kind*8 + {rays, node visits, prim tests, occluded/hit, wave-iterations*64, found}]
         const int base = SHADOW ? 8 : 0;
@@ -358,6 +417,7 @@ MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_
         for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
         if (lane_id() == 0) atomicAdd(&S.dbg[base + 4], (unsigned long long)mx * 64ull);
         atomicAdd(&S.dbg[base + 5], (unsigned long long)(SHADOW ? (st.found ? 1 : 0) : 0));
+        atomicMax(&S.dbg[SHADOW ? 7 : 6], (unsigned long long)st.maxsp);  // deepest stack of any ray (1000: an entry was dropped)
     }
 #endif
     return TraceResult{st.best_t, st.best_prim, st.best_mat, !st.occluded && st.found};
@@ -368,7 +428,7 @@ MCPT_DI uint4 pack_hit(double t, int32_t prim, uint32_t mat_bits) {  // {t lo, t
     return make_uint4((uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)prim, mat_bits);
 }
 
-template <int STK>
+template <int STK, bool RETRY>
 __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n_host, const uint32_t *__restrict__ n_dev,
                                                           const float4 *__restrict__ ray_o, const float4 *__restrict__ ray_d,
                                                           uint4 *__restrict__ hit) {
@@ -378,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n
     // grid-stride: when the length is only known on the device the host sizes the grid from an estimate
     for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += gridDim.x * kBlock) {
         const Ray r = make_ray(ld3(ray_o[i]), ld3(ray_d[i]));
-        const TraceResult tr = traverse<false, STK>(S, r, 0.f, stk, tid);
+        const TraceResult tr = traverse<false, STK, RETRY>(S, r, 0.f, stk, tid);
         hit[i] = pack_hit(tr.t, tr.prim, tr.mat_bits);
     }
 }
@@ -403,7 +463,7 @@ constexpr uint32_t kRaysPerLane = MCPT_RAYS_PER_LANE, kRefillMin = MCPT_REFILL_M
 #ifndef MCPT_REFILL_WAVES
 #define MCPT_REFILL_WAVES 7
 #endif
-template <int STK>
+template <int STK, bool RETRY>
 __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k_trace_closest_refill(DevScene S, uint32_t n_host, const uint32_t *__restrict__ n_dev,
                                                                  const float4 *__restrict__ ray_o, const float4 *__restrict__ ray_d,
                                                                  uint4 *__restrict__ hit) {
@@ -424,11 +484,21 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
         uint32_t best_mat = 0;
         int32_t cur = kNoWork, leaf = kNoWork;
         int sp = 0;
+        bool dropped = false;  // RETRY: this ray lost a stack entry (see stk_push)
         while (true) {
             // ---- finished lanes: store, refill
             const bool idle = cur == kNoWork && leaf == kNoWork;
             if (idle && my >= 0) {
-                hit[my] = pack_hit(best_t, best_prim, best_mat);
+                if (RETRY && dropped) {  // trace it again with the scratch stack
+                    TraceState st2;
+#ifdef MCPT_TRAVERSAL_STATS
+                    st2.nv = st2.nt = st2.iters = st2.maxsp = 0;
+#endif
+                    traverse_again<false>(S, r, 0.f, stk, tid, false, st2);
+                    hit[my] = pack_hit(st2.best_t, st2.best_prim, st2.best_mat);
+                } else {
+                    hit[my] = pack_hit(best_t, best_prim, best_mat);
+                }
                 my = -1;
             }
             const unsigned long long im = __ballot(idle);
@@ -438,7 +508,7 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
                 if (idle && idx < end) {
                     r = make_ray(ld3(ray_o[idx]), ld3(ray_d[idx]));
                     if (!ray_is_plain(r)) {  // rare (a zero direction component): the NaN-faithful generic path, right away
-                        const TraceResult tr = traverse<false, STK>(S, r, 0.f, stk, tid);
+                        const TraceResult tr = traverse<false, STK, RETRY>(S, r, 0.f, stk, tid);
                         hit[idx] = pack_hit(tr.t, tr.prim, tr.mat_bits);
                     } else {
                         my = (int32_t)idx;
@@ -448,6 +518,7 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
                         best_prim = -1;
                         best_mat = 0;
                         sp = 0;
+                        dropped = false;
                         float tm, tx;
                         if (box_hit<true>(S.root_min, S.root_max, r, tm, tx)) {
                             if (S.root >= 0) cur = S.root;
@@ -472,18 +543,18 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
                     if (hl && hr) {
                         const bool swap = tr < tl;
                         const int32_t nearc = swap ? right : left, farc = swap ? left : right;
-                        if (sp < STK) stk[sp++][tid] = farc;
+                        stk_push<STK, false>(stk, nullptr, tid, sp, farc, dropped);
                         cur = nearc;
                     } else if (hl) {
                         cur = left;
                     } else if (hr) {
                         cur = right;
                     } else {
-                        cur = (sp == 0) ? kNoWork : stk[--sp][tid];
+                        cur = (sp == 0) ? kNoWork : stk_pop<STK, false>(stk, nullptr, tid, sp);
                     }
                     if (cur < 0 && cur != kNoWork && leaf == kNoWork) {
                         leaf = cur;
-                        cur = (sp == 0) ? kNoWork : stk[--sp][tid];
+                        cur = (sp == 0) ? kNoWork : stk_pop<STK, false>(stk, nullptr, tid, sp);
                     }
                 }
                 if (__popcll(__ballot(leaf == kNoWork && cur >= 0)) <= kLeafVote) break;
@@ -514,7 +585,7 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
                 leaf = kNoWork;
                 if (cur < 0 && cur != kNoWork) {
                     leaf = cur;
-                    cur = (sp == 0) ? kNoWork : stk[--sp][tid];
+                    cur = (sp == 0) ? kNoWork : stk_pop<STK, false>(stk, nullptr, tid, sp);
                 }
             }
         }
@@ -524,7 +595,7 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
 // Shadow queue consumer: a fixed grid strides over the queue, whose length is only known on the device.
 // Items [0, n_found) are the front of the arrays (light sample already found: occluder search only), the next n_window
 // items are read from the back (window search first), so that the long occluder searches fill whole waves.
-template <int STK>
+template <int STK, bool RETRY>
 __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Counters *__restrict__ counters, int next_idx, uint32_t cap,
                                                          const float4 *__restrict__ shq_o, const float4 *__restrict__ shq_d,
                                                          float *__restrict__ contrib) {
@@ -537,7 +608,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Count
         const uint32_t e = found ? i : cap - 1u - (i - n_found);
         const float4 o = shq_o[e], d = shq_d[e];
         const Ray r = make_ray(ld3(o), ld3(d));
-        const TraceResult tr = traverse<true, STK>(S, r, d.w, stk, tid, found);
+        const TraceResult tr = traverse<true, STK, RETRY>(S, r, d.w, stk, tid, found);
         if (!tr.visible) contrib[__float_as_uint(o.w)] = 0.f;  // Scene.cpp:74-79: an invisible sample adds nothing
     }
 }
@@ -613,7 +684,7 @@ MCPT_DI void camera_ray(const CameraConst &cam, uint32_t seed, uint32_t m, uint3
 //   miss (Scene.cpp:88-95) ............ result[3 channels] = environment, no records
 //   depth-0 emitter (Scene.cpp:102-107)  result[3 channels] = clamp(0,1, emission * |wo.n|), no records
 //   surface ........................... one ray + hit entry, three fresh path records, three clamp-stack slots
-template <int STK>
+template <int STK, bool RETRY>
 __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam, RenderConst C, Wave next, int next_idx, int q,
                                                     uint32_t first_sample, uint32_t n_samples) {
     __shared__ int32_t stk[STK][kBlock];
@@ -635,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
         const Ray r = make_ray(pos, dir);
         const int4 cd = C.pixel_cand ? C.pixel_cand[pl] : make_int4(kCandTraverse, 0, 0, 0);
         if (cd.x == kCandTraverse) {
-            tr = traverse<false, STK>(S, r, 0.f, stk, tid);
+            tr = traverse<false, STK, RETRY>(S, r, 0.f, stk, tid);
         } else {
             // every primitive a ray of this pixel can hit is in the list (csrc/mcpt_cull.hip): test those, with the traversal's tie rule
             const int32_t cs[4] = {cd.x, cd.y, cd.z, cd.w};
@@ -1282,15 +1353,35 @@ void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, uint32_t
     hipLaunchKernelGGL(k_init_free, dim3(blocks(pool)), dim3(kBlock), 0, s, free_slots, c, pool, start, mask);
 }
 
+// Stack flavour by tree height (see stk_push): <= 17 levels: 16 LDS entries; <= 20: kStkB; <= 24: 24; deeper: the retry flavour (16 LDS entries).
+// (-DMCPT_LDS_ONLY_STACKS: the former 24 / 32 / 48-entry LDS stacks for deep trees, for A/B measurements; -DMCPT_FORCE_RETRY, the
+// checking build: the retry flavour for every tree, with -DMCPT_STK_RETRY=4 LDS entries, so that most rays are traced again.)
+#ifdef MCPT_LDS_ONLY_STACKS
+#define MCPT_STACK_DISPATCH(height, KERNEL, ...)                                                   \
+    do {                                                                                           \
+        if ((height) <= 17) hipLaunchKernelGGL((KERNEL<16, false>), __VA_ARGS__);                  \
+        else if ((height) <= 20) hipLaunchKernelGGL((KERNEL<kStkB, false>), __VA_ARGS__);          \
+        else if ((height) <= 24) hipLaunchKernelGGL((KERNEL<24, false>), __VA_ARGS__);             \
+        else if ((height) <= 32) hipLaunchKernelGGL((KERNEL<32, false>), __VA_ARGS__);             \
+        else hipLaunchKernelGGL((KERNEL<kMaxBvhHeight, false>), __VA_ARGS__);                      \
+    } while (0)
+#elif defined(MCPT_FORCE_RETRY)
+#define MCPT_STACK_DISPATCH(height, KERNEL, ...) hipLaunchKernelGGL((KERNEL<kStkRetry, true>), __VA_ARGS__)
+#else
+#define MCPT_STACK_DISPATCH(height, KERNEL, ...)                                                   \
+    do {                                                                                           \
+        if ((height) <= 17) hipLaunchKernelGGL((KERNEL<16, false>), __VA_ARGS__);                  \
+        else if ((height) <= 20) hipLaunchKernelGGL((KERNEL<kStkB, false>), __VA_ARGS__);          \
+        else if ((height) <= 24) hipLaunchKernelGGL((KERNEL<24, false>), __VA_ARGS__);             \
+        else hipLaunchKernelGGL((KERNEL<kStkRetry, true>), __VA_ARGS__);                           \
+    } while (0)
+#endif
+
 void launch_primary(const DevScene &S, const CameraConst &cam, const RenderConst &C, Wave next, int next_idx, int parity,
                     uint32_t first_sample, uint32_t n_samples, hipStream_t s) {
     if (n_samples == 0) return;
     const dim3 g(blocks(n_samples)), b(kBlock);
-    if (S.height <= 16) hipLaunchKernelGGL((k_primary<16>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
-    else if (S.height <= 20) hipLaunchKernelGGL((k_primary<20>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
-    else if (S.height <= 24) hipLaunchKernelGGL((k_primary<24>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
-    else if (S.height <= 32) hipLaunchKernelGGL((k_primary<32>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
-    else hipLaunchKernelGGL((k_primary<kMaxBvhHeight>), g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
+    MCPT_STACK_DISPATCH(S.height, k_primary, g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
 }
 
 void launch_generate_explicit(const RenderConst &C, Wave next, int next_idx, uint32_t n, hipStream_t s) {
@@ -1304,27 +1395,18 @@ void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const
     hipLaunchKernelGGL(k_camera_rays, dim3(blocks(n)), dim3(kBlock), 0, s, cam, seed, n, pixel, sample, o, d);
 }
 
-// The LDS stack depth is picked from the scene's tree height (one pushed reference per level at most).
 void launch_trace_closest(const DevScene &S, uint32_t n, const uint32_t *n_dev, const float4 *ray_o, const float4 *ray_d, uint4 *hit,
                           hipStream_t s) {
     if (n == 0) return;
 #ifndef MCPT_NO_REFILL
     if (S.qnodes && !S.inst) {  // the common configuration: lanes refill from the wave's chunk of rays
         const dim3 g((n + kBlock * kRaysPerLane - 1) / (kBlock * kRaysPerLane)), b(kBlock);
-        if (S.height <= 16) hipLaunchKernelGGL((k_trace_closest_refill<16>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
-        else if (S.height <= 20) hipLaunchKernelGGL((k_trace_closest_refill<20>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
-        else if (S.height <= 24) hipLaunchKernelGGL((k_trace_closest_refill<24>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
-        else if (S.height <= 32) hipLaunchKernelGGL((k_trace_closest_refill<32>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
-        else hipLaunchKernelGGL((k_trace_closest_refill<kMaxBvhHeight>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
+        MCPT_STACK_DISPATCH(S.height, k_trace_closest_refill, g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
         return;
     }
 #endif
     const dim3 g(blocks(n)), b(kBlock);
-    if (S.height <= 16) hipLaunchKernelGGL((k_trace_closest<16>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
-    else if (S.height <= 20) hipLaunchKernelGGL((k_trace_closest<20>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
-    else if (S.height <= 24) hipLaunchKernelGGL((k_trace_closest<24>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
-    else if (S.height <= 32) hipLaunchKernelGGL((k_trace_closest<32>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
-    else hipLaunchKernelGGL((k_trace_closest<kMaxBvhHeight>), g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
+    MCPT_STACK_DISPATCH(S.height, k_trace_closest, g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
 }
 
 void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_grid, hipStream_t s) {
@@ -1338,13 +1420,8 @@ void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_i
     // The queue length is only known on the device.  The grid covers the upper bound (capped at 1024 workgroups per
     // CU, far more than are resident, so the hardware balances uneven rays dynamically: a persistent 8-per-CU grid
     // was 30 % slower on the Cornell box); workgroups past the end of the queue exit at once, longer queues stride.
-    const int stk = S.height <= 16 ? 16 : (S.height <= 20 ? 20 : (S.height <= 24 ? 24 : (S.height <= 32 ? 32 : kMaxBvhHeight)));
     const dim3 g(std::min<uint32_t>(blocks(n_max), 256u * per_cu)), b(kBlock);
-    if (stk == 16) hipLaunchKernelGGL((k_trace_shadow<16>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
-    else if (stk == 20) hipLaunchKernelGGL((k_trace_shadow<20>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
-    else if (stk == 24) hipLaunchKernelGGL((k_trace_shadow<24>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
-    else if (stk == 32) hipLaunchKernelGGL((k_trace_shadow<32>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
-    else hipLaunchKernelGGL((k_trace_shadow<kMaxBvhHeight>), g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
+    MCPT_STACK_DISPATCH(S.height, k_trace_shadow, g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
 }
 
 void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, Scratch X, int cur_idx, uint32_t n_cur_max,

@@ -65,3 +65,29 @@ def test_skipped_direct_lighting_is_exactly_zero(pkg, hip, hip_check, oracle, na
         ref, _ = oracle.OracleScene(sd).render(spp=8, seed=3)
         gpu, _ = hip.HipScene(sd).render(spp=8, seed=3)
         assert pkg.pngio.psnr_u8(pkg.pngio.tonemap_u8(ref), pkg.pngio.tonemap_u8(gpu)) >= 60.0
+
+
+@pytest.mark.parametrize("builder", ["sah", "lbvh", "reference"])
+def test_retry_flavour_of_the_traversal_stack(pkg, hip, hip_check, builder):
+    """Trees deeper than 20 levels are traversed with 16 stack entries in LDS; a ray that would need more loses an entry, is marked,
+    and is traced again with a per-lane stack in scratch memory (stk_push / traverse_again in csrc/mcpt_kernels.hip) -- which no ray
+    of these scenes needs.  The checking build uses that flavour for every tree with FOUR LDS entries, so most of its rays are
+    traced twice: same intersections, same frames, same counters."""
+    rng = np.random.default_rng(11)
+    for sd in (pkg.scenes.chess_scene(width=160, height=90, spp=4), pkg.scenes.chess_high(160, 90, 4), pkg.scenes.cornell_demo(64, 64, 4)):
+        prod, chk = hip.HipScene(sd, builder=builder), hip.HipScene(sd, library=hip_check, builder=builder)
+        assert prod.info()["bvh_height"] == chk.info()["bvh_height"]
+        n = 30000
+        w, h = int(sd.camera["width"]), int(sd.camera["height"])
+        o, d = prod.camera_rays(rng.integers(0, w * h, n).astype(np.uint32), rng.integers(0, 64, n).astype(np.uint32), seed=3)
+        d = d.copy()
+        d[: n // 10, 1] = 0.0  # (a zero component: the NaN-faithful slab test, generic loop)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        a, b = prod.intersect(o, d), chk.intersect(o, d)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True)
+        fa, sa = prod.render(spp=4, seed=5)
+        fb, sb = chk.render(spp=4, seed=5)
+        assert np.array_equal(fa, fb, equal_nan=True) and sa.vertices == sb.vertices and sa.shadow_rays == sb.shadow_rays
+        prod.close()
+        chk.close()

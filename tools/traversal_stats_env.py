@@ -8,5 +8,5 @@ for name, sd in (("chess", pkg.scenes.chess_scene(width=480, height=270, spp=16)
     hs.render(spp=16, seed=1)
     c = hs.debug_counters().astype(np.float64)
     print(name, sys.argv[1:], "height", hs.info()["bvh_height"], "closest: rays %d, node visits/ray %.2f, prim tests/ray %.2f, hit %.3f, lane utilisation %.3f | shadow: rays %d, visits %.2f, tests %.2f, util %.3f"
-          % (c[0], c[1] / c[0], c[2] / c[0], c[3] / c[0], (c[1] + c[2]) / c[4], c[8], c[9] / max(c[8], 1), c[10] / max(c[8], 1), (c[9] + c[10]) / max(c[12], 1)), flush=True)
+          % (c[0], c[1] / c[0], c[2] / c[0], c[3] / c[0], (c[1] + c[2]) / c[4], c[8], c[9] / max(c[8], 1), c[10] / max(c[8], 1), (c[9] + c[10]) / max(c[12], 1)), "| deepest stack: closest %d, shadow %d" % (c[6], c[7]), flush=True)
     hs.close()
