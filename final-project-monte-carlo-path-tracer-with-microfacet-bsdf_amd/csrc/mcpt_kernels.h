@@ -101,9 +101,10 @@ struct CameraConst {
 // Traversal-stack entries per lane the traversal kernels provide for a tree of this height (a ray holds at most one child reference
 // per inner ancestor, i.e. height - 1).  0: the tree is too deep for any instantiation.
 #ifndef MCPT_STK_B
-#define MCPT_STK_B 19
+#define MCPT_STK_B 20
 #endif
-constexpr int kStkB = MCPT_STK_B;  // entries for trees of height 17..20 (19 is exact for height 20, and 19 KB + the allocation block of k_primary still fit 8 workgroups into the 160 KB of a CU; 20 fit 7: +1 % on the chess frame)
+constexpr int kStkB = MCPT_STK_B;  // entries for trees of height 18..20.  (19 would be exact for height 20 and lets 8 instead of 7 workgroups of k_primary /
+// k_trace_shadow share a CU: they gain what k_direct beside them loses -- frame rate +1 %, +0.1 %, -0.8 % in three A/B runs: no change.)
 inline int traversal_stack_entries(int height) {
     return height <= 17 ? 16 : (height <= 20 ? kStkB : (height <= kMaxBvhHeight ? kMaxBvhHeight : 0));  // (deeper than 20: 16 in LDS, and the scratch stack of kMaxBvhHeight entries for rays that need more)
 }

@@ -142,7 +142,7 @@ struct TraceState {
 // The per-lane traversal stack: STK entries in LDS (column `tid` of stk[][kBlock]).  A ray holds at most one entry per inner ancestor
 // (tree height - 1), but the deepest stack any ray of the chess frames reaches is 11-12 entries (SAH trees of height 20-24) or 14-15
 // (LBVH, height 27-36; tools/traversal_stats_env.py), while every LDS entry costs 1 KB per workgroup and, beyond 19, resident
-// workgroups (20-22 entries: 7 per CU, 23-26: 6, 32: 5, 48: 3).  Three flavours:
+// workgroups (up to 19 entries: 8 per CU, 20-22: 7, 23-26: 6, 32: 5, 48: 3).  Three flavours:
 //   plain   trees of up to 24 levels: STK >= height - 1 LDS entries, a push can never fail.
 //   retry   deeper trees (RETRY): 16 LDS entries; a push onto a full stack drops the entry and marks the ray (`dropped`).  The walk goes on
 //           (it only visits less) and its result is thrown away: a marked ray is traced again, from the start, by the
@@ -157,21 +157,17 @@ struct TraceState {
 #define MCPT_STK_RETRY 16
 #endif
 constexpr int kStkRetry = MCPT_STK_RETRY;  // LDS entries of the retry flavour (the checking build: 4, and every tree uses it)
-template <int STK, bool SCR>
-MCPT_DI void stk_push(int32_t (*stk)[kBlock], int32_t *scr, int tid, int &sp, int32_t v, bool &dropped) {
-    if (SCR) {
-        if (sp < kMaxBvhHeight) scr[sp++] = v;  // (never full: mcpt_scene_create refuses trees deeper than kMaxBvhHeight)
-    } else if (sp < STK) {
-        stk[sp++][tid] = v;
-    } else {
-        dropped = true;  // plain flavour: never (STK >= height - 1); retry flavour: the ray is traced again
-    }
-}
-template <int STK, bool SCR>
-MCPT_DI int32_t stk_pop(int32_t (*stk)[kBlock], const int32_t *scr, int tid, int &sp) {  // sp > 0
-    --sp;
-    return SCR ? scr[sp] : stk[sp][tid];
-}
+// (Macros, not functions: the plain flavour must compile to exactly the statements it had before the other flavours existed.)
+#define MCPT_STK_PUSH(v)                                                                                           \
+    do {                                                                                                           \
+        if (SCR) {                                                                                                 \
+            if (sp < kMaxBvhHeight) scr[sp++] = (v); /* never full: mcpt_scene_create refuses deeper trees */      \
+        } else {                                                                                                   \
+            if (sp < STK) stk[sp++][tid] = (v); /* plain: never full (STK >= height - 1, asserted at creation) */  \
+            else if (MARK) st.dropped = true;   /* retry: the entry is lost, the ray is traced again */            \
+        }                                                                                                          \
+    } while (0)
+#define MCPT_STK_POP() (SCR ? scr[--sp] : stk[--sp][tid]) /* sp > 0 */
 
 // Speculative while-while loop (Aila & Laine 2009, "Understanding the efficiency of ray traversal on GPUs").  A plain
 // `if (inner) node-step else leaf-test` loop makes a wave pay for BOTH bodies in nearly every iteration (with 64 lanes, some lane
@@ -192,7 +188,7 @@ MCPT_DI int32_t stk_pop(int32_t (*stk)[kBlock], const int32_t *scr, int tid, int
 constexpr int32_t kNoWork = (int32_t)0x80000000;   // neither an inner node (>= 0) nor a leaf (~index, index < 2^31 - 2)
 constexpr int32_t kInstExit = (int32_t)0x80000001; // stack marker: the subtree of the current instance is exhausted
 constexpr int kLeafVote = 12;
-template <int MODE, int STK, bool SCR, bool FAST, bool QUANT, bool INST>
+template <int MODE, int STK, bool SCR, bool MARK, bool FAST, bool QUANT, bool INST>
 MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int32_t *scr, int tid, TraceState &st) {
     QRay qr;
     if (QUANT) qr = make_qray(S, r);
@@ -222,14 +218,14 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
                     rb.o = r.o;
                     prim_base = 0;
                     if (QUANT) qr.b = make_qray(S, r).b;
-                    cur = (sp == 0) ? kNoWork : stk_pop<STK, SCR>(stk, scr, tid, sp);
+                    cur = (sp == 0) ? kNoWork : MCPT_STK_POP();
                 }
                 if (cur > kInstExit && cur < 0 && (uint32_t)(~cur) >= n_leaf_prims) {  // an instance: enter its prototype's subtree
                     const InstRec I = S.inst[(uint32_t)(~cur) - n_leaf_prims];
                     rb.o = mk3(r.o.x - I.shift[0], r.o.y - I.shift[1], r.o.z - I.shift[2]);
                     prim_base = I.first_tri;
                     if (QUANT) qr.b = make_qray(S, rb).b;
-                    stk_push<STK, SCR>(stk, scr, tid, sp, kInstExit, st.dropped);
+                    MCPT_STK_PUSH(kInstExit);
                     cur = I.root;
                 }
             }
@@ -270,7 +266,7 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
 #ifdef MCPT_TRAVERSAL_STATS
                     const int sp_before = sp;
 #endif
-                    stk_push<STK, SCR>(stk, scr, tid, sp, farc, st.dropped);
+                    MCPT_STK_PUSH(farc);
 #ifdef MCPT_TRAVERSAL_STATS
                     st.maxsp = max(st.maxsp, sp == sp_before ? 1000u : (unsigned)sp);  // (1000: a dropped entry)
 #endif
@@ -280,11 +276,11 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
                 } else if (hr) {
                     cur = right;
                 } else {
-                    cur = (sp == 0) ? kNoWork : stk_pop<STK, SCR>(stk, scr, tid, sp);
+                    cur = (sp == 0) ? kNoWork : MCPT_STK_POP();
                 }
                 if (cur < 0 && (uint32_t)(~cur) < n_leaf_prims && leaf == kNoWork) {  // first leaf of the round: park it and keep traversing
                     leaf = ~(prim_base + ~cur);  // (a global primitive id from here on)
-                    cur = (sp == 0) ? kNoWork : stk_pop<STK, SCR>(stk, scr, tid, sp);
+                    cur = (sp == 0) ? kNoWork : MCPT_STK_POP();
                 }
             }
             // a lane can still make progress on nodes if it holds an inner node (or, INST, an instance / exit marker)
@@ -329,7 +325,7 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
             leaf = kNoWork;
             if (cur < 0 && (uint32_t)(~cur) < n_leaf_prims) {  // a second leaf was waiting: park it for the next round
                 leaf = ~(prim_base + ~cur);
-                cur = (sp == 0) ? kNoWork : stk_pop<STK, SCR>(stk, scr, tid, sp);
+                cur = (sp == 0) ? kNoWork : MCPT_STK_POP();
             }
         }
         if (cur == kNoWork && leaf == kNoWork) return;
@@ -348,61 +344,65 @@ MCPT_DI bool prim_hit(const DevScene &S, int32_t prim, const Ray &r, double &t) 
     return h;
 }
 
-// One complete query with one stack flavour.  found: shadow queries only -- the window search is already settled (k_direct found the
-// sampled primitive in the window).
-template <bool SHADOW, int STK, bool SCR>
-MCPT_DI void traverse_once(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int32_t *scr, int tid, bool found, TraceState &st) {
+// The dispatch of one query over the loop's instantiations: slab-test flavour (wave-uniform: the exact NaN-faithful chain only when some
+// lane of the wave has a non-finite reciprocal, i.e. a zero direction component; otherwise the bit-identical max3/min3 form), node
+// format, instancing.  Shadow queries, Scene.cpp:74-75: a light sample counts iff the CLOSEST hit lies within EPSILON of the light
+// distance, i.e. iff some hit lies in the window AND no hit lies at or below dist - EPSILON; `found`: the window search is already
+// settled (k_direct found the sampled primitive in the window).
+#define MCPT_TL(MODE, FAST, STKN, SCRB, MARKB, SCRP)                                                                  \
+    do {                                                                                                              \
+        if (S.inst) {                                                                                                 \
+            if (S.qnodes) traverse_loop<MODE, STKN, SCRB, MARKB, FAST, true, true>(S, r, dist, stk, SCRP, tid, st);   \
+            else traverse_loop<MODE, STKN, SCRB, MARKB, FAST, false, true>(S, r, dist, stk, SCRP, tid, st);           \
+        } else {                                                                                                      \
+            if (S.qnodes) traverse_loop<MODE, STKN, SCRB, MARKB, FAST, true, false>(S, r, dist, stk, SCRP, tid, st);  \
+            else traverse_loop<MODE, STKN, SCRB, MARKB, FAST, false, false>(S, r, dist, stk, SCRP, tid, st);          \
+        }                                                                                                             \
+    } while (0)
+#define MCPT_QUERY(STKN, SCRB, MARKB, SCRP)                                        \
+    do {                                                                           \
+        const bool plain = __all(ray_is_plain(r)) != 0;                            \
+        if (SHADOW) {                                                              \
+            if (plain) {                                                           \
+                if (!found) MCPT_TL(kWindow, true, STKN, SCRB, MARKB, SCRP);       \
+                if (st.found && !st.occluded) MCPT_TL(kOccluder, true, STKN, SCRB, MARKB, SCRP);  \
+            } else {                                                               \
+                if (!found) MCPT_TL(kWindow, false, STKN, SCRB, MARKB, SCRP);      \
+                if (st.found && !st.occluded) MCPT_TL(kOccluder, false, STKN, SCRB, MARKB, SCRP); \
+            }                                                                      \
+        } else if (plain) {                                                        \
+            MCPT_TL(kClosest, true, STKN, SCRB, MARKB, SCRP);                      \
+        } else {                                                                   \
+            MCPT_TL(kClosest, false, STKN, SCRB, MARKB, SCRP);                     \
+        }                                                                          \
+    } while (0)
+
+// The scratch flavour: the ray again, from the start, with the whole stack in a per-lane array (see MCPT_STK_PUSH).
+template <bool SHADOW>
+MCPT_DI void traverse_again(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, bool found, TraceState &st) {
+    int32_t scr[kMaxBvhHeight];
     st.best_t = DBL_MAX;
     st.best_prim = -1;
     st.best_mat = 0;
     st.occluded = false;
     st.found = found;
     st.dropped = false;
-#define TL(MODE, FAST)                                                                                     \
-    do {                                                                                                   \
-        if (S.inst) {                                                                                      \
-            if (S.qnodes) traverse_loop<MODE, STK, SCR, FAST, true, true>(S, r, dist, stk, scr, tid, st);  \
-            else traverse_loop<MODE, STK, SCR, FAST, false, true>(S, r, dist, stk, scr, tid, st);          \
-        } else {                                                                                           \
-            if (S.qnodes) traverse_loop<MODE, STK, SCR, FAST, true, false>(S, r, dist, stk, scr, tid, st); \
-            else traverse_loop<MODE, STK, SCR, FAST, false, false>(S, r, dist, stk, scr, tid, st);         \
-        }                                                                                                  \
-    } while (0)
-    // Wave-uniform choice of the slab-test flavour: the exact NaN-faithful chain only when some lane of the wave
-    // has a non-finite reciprocal (a zero direction component); otherwise the bit-identical max3/min3 form.
-    const bool plain = __all(ray_is_plain(r)) != 0;
-    if (SHADOW) {
-        // Scene.cpp:74-75: a light sample counts iff the CLOSEST hit lies within EPSILON of the light distance,
-        // i.e. iff some hit lies in the window AND no hit lies at or below dist - EPSILON.
-        if (plain) {
-            if (!found) TL(kWindow, true);
-            if (st.found && !st.occluded) TL(kOccluder, true);
-        } else {
-            if (!found) TL(kWindow, false);
-            if (st.found && !st.occluded) TL(kOccluder, false);
-        }
-    } else if (plain) {
-        TL(kClosest, true);
-    } else {
-        TL(kClosest, false);
-    }
-#undef TL
-}
-
-// The scratch flavour: the ray again, from the start, with the whole stack in a per-lane array (see stk_push).
-template <bool SHADOW>
-MCPT_DI void traverse_again(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, bool found, TraceState &st) {
-    int32_t scr[kMaxBvhHeight];
-    traverse_once<SHADOW, 0, true>(S, r, dist, stk, scr, tid, found, st);
+    MCPT_QUERY(0, true, false, scr);
 }
 
 template <bool SHADOW, int STK, bool RETRY>
 MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, bool found = false) {
     TraceState st;
+    st.best_t = DBL_MAX;
+    st.best_prim = -1;
+    st.best_mat = 0;
+    st.occluded = false;
+    st.found = found;
+    if (RETRY) st.dropped = false;
 #ifdef MCPT_TRAVERSAL_STATS
     st.nv = st.nt = st.iters = st.maxsp = 0;
 #endif
-    traverse_once<SHADOW, STK, false>(S, r, dist, stk, nullptr, tid, found, st);
+    MCPT_QUERY(STK, false, RETRY, nullptr);
     if (RETRY) {
         if (st.dropped) traverse_again<SHADOW>(S, r, dist, stk, tid, found, st);
     }
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
         uint32_t best_mat = 0;
         int32_t cur = kNoWork, leaf = kNoWork;
         int sp = 0;
-        bool dropped = false;  // RETRY: this ray lost a stack entry (see stk_push)
+        bool dropped = false;  // RETRY: this ray lost a stack entry (see MCPT_STK_PUSH)
         while (true) {
             // ---- finished lanes: store, refill
             const bool idle = cur == kNoWork && leaf == kNoWork;
@@ -543,18 +543,19 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
                     if (hl && hr) {
                         const bool swap = tr < tl;
                         const int32_t nearc = swap ? right : left, farc = swap ? left : right;
-                        stk_push<STK, false>(stk, nullptr, tid, sp, farc, dropped);
+                        if (sp < STK) stk[sp++][tid] = farc;
+                        else if (RETRY) dropped = true;
                         cur = nearc;
                     } else if (hl) {
                         cur = left;
                     } else if (hr) {
                         cur = right;
                     } else {
-                        cur = (sp == 0) ? kNoWork : stk_pop<STK, false>(stk, nullptr, tid, sp);
+                        cur = (sp == 0) ? kNoWork : stk[--sp][tid];
                     }
                     if (cur < 0 && cur != kNoWork && leaf == kNoWork) {
                         leaf = cur;
-                        cur = (sp == 0) ? kNoWork : stk_pop<STK, false>(stk, nullptr, tid, sp);
+                        cur = (sp == 0) ? kNoWork : stk[--sp][tid];
                     }
                 }
                 if (__popcll(__ballot(leaf == kNoWork && cur >= 0)) <= kLeafVote) break;
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
                 leaf = kNoWork;
                 if (cur < 0 && cur != kNoWork) {
                     leaf = cur;
-                    cur = (sp == 0) ? kNoWork : stk_pop<STK, false>(stk, nullptr, tid, sp);
+                    cur = (sp == 0) ? kNoWork : stk[--sp][tid];
                 }
             }
         }
@@ -1353,7 +1354,7 @@ void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, uint32_t
     hipLaunchKernelGGL(k_init_free, dim3(blocks(pool)), dim3(kBlock), 0, s, free_slots, c, pool, start, mask);
 }
 
-// Stack flavour by tree height (see stk_push): <= 17 levels: 16 LDS entries; <= 20: kStkB; <= 24: 24; deeper: the retry flavour (16 LDS entries).
+// Stack flavour by tree height (see MCPT_STK_PUSH): <= 17 levels: 16 LDS entries; <= 20: kStkB; <= 24: 24; deeper: the retry flavour (16 LDS entries).
 // (-DMCPT_LDS_ONLY_STACKS: the former 24 / 32 / 48-entry LDS stacks for deep trees, for A/B measurements; -DMCPT_FORCE_RETRY, the
 // checking build: the retry flavour for every tree, with -DMCPT_STK_RETRY=4 LDS entries, so that most rays are traced again.)
 #ifdef MCPT_LDS_ONLY_STACKS

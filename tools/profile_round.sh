@@ -34,5 +34,6 @@ python3 $R/bench.py --n-dir 32 --no-cpu-baseline > $O/bench_config4_chess_spp204
 python3 $R/bench.py --scene cornell_demo --no-cpu-baseline > $O/bench_cornell_demo_1080p.json 2>> $O/bench.err || exit 1
 python3 $R/bench.py --scene chess_high --no-cpu-baseline > $O/bench_chess_high_sah.json 2>> $O/bench.err || exit 1
 MCPT_BVH=lbvh python3 $R/bench.py --scene chess_high --no-cpu-baseline > $O/bench_chess_high_lbvh.json 2>> $O/bench.err || exit 1
+MCPT_BVH=lbvh python3 $R/bench.py --no-cpu-baseline > $O/bench_chess_lbvh.json 2>> $O/bench.err || exit 1
 echo "config benches done"
 ls -la $O
