@@ -79,3 +79,55 @@ def test_single_primitive_and_options_errors(pkg, hip):
     d = hip._make_desc(sd, keep)
     h = C.c_void_p()
     assert hip.lib().mcpt_scene_create_ex(C.byref(d), -1, C.byref(opt), C.byref(h)) == 1
+
+
+def _chain(pkg, n):
+    """n triangles that all cover the square [-1, 0]^2 of their plane z = const, the k-th one reaching out to 2^(k // 3) along the
+    axis k % 3 (long in x, long in y, or far away in z): every centroid has its own leading bit in the interleaved Morton code, so
+    the linear BVH is one chain of about n levels, and a ray along +z through that square meets every box of it."""
+    base = pkg.scenes.cornell_rc(32, 32, 1)
+    tri = np.zeros(n, dtype=base.triangles.dtype)
+    for k in range(n):
+        L = np.float32(3.0 * 2.0 ** (k // 3 + 1))
+        a = k % 3
+        z = np.float32(0.01 * k) if a < 2 else L
+        if a == 0:
+            v = [[-1, -1, z], [L, -1, z], [-1, 1, z]]
+        elif a == 1:
+            v = [[-1, -1, z], [1, -1, z], [-1, L, z]]
+        else:
+            v = [[-1, -1, z], [3, -1, z], [-1, 3, z]]
+        tri["v0"][k], tri["v1"][k], tri["v2"][k] = np.float32(v)
+    obj = np.zeros(1, dtype=base.objects.dtype)
+    obj["kind"], obj["material"], obj["first_tri"], obj["n_tri"] = 0, 0, 0, n
+    return pkg.scenes.SceneData(triangles=tri, materials=base.materials[:1].copy(), objects=obj, background=base.background,
+                                env_pixels=None, camera=base.camera, rr_rate=base.rr_rate)
+
+
+def test_deep_trees_are_exact_and_too_deep_ones_are_refused(pkg, oracle, hip):
+    """Trees deeper than 24 levels run the retry flavour of the traversal stack (16 LDS entries, rays that need more are traced again
+    with a scratch stack); a tree deeper than the scratch stack (48) is refused at creation, loudly, with the way out in the message."""
+    rng = np.random.default_rng(4)
+    heights = []
+    for n in (24, 36, 45, 63):
+        sd = _chain(pkg, n)
+        try:
+            hs = hip.HipScene(sd, builder="lbvh")
+        except RuntimeError as e:
+            assert "deeper than the traversal stack" in str(e) and "MCPT_BUILD_SAH" in str(e)
+            heights.append(None)
+            continue
+        h = hs.info()["bvh_height"]
+        heights.append(h)
+        assert h <= 48
+        m = 20000
+        o = np.concatenate([rng.uniform(-0.9, -0.1, (m, 2)), np.full((m, 1), -5.0)], axis=1).astype(np.float32)
+        d = np.concatenate([rng.normal(0, 0.02, (m, 2)), np.ones((m, 1))], axis=1).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        t_ref, p_ref = oracle.OracleScene(sd).intersect(o, d)
+        t_gpu, p_gpu = hs.intersect(o, d)
+        assert np.array_equal(p_ref, p_gpu) and np.array_equal(t_ref[p_ref >= 0], t_gpu[p_ref >= 0])
+        t_sah, p_sah = hip.HipScene(sd, builder="sah").intersect(o, d)
+        assert np.array_equal(p_sah, p_gpu)
+    print("\n[lbvh] chain scenes: heights", heights)
+    assert any(h is not None and h > 24 for h in heights), heights  # the retry flavour was in use
