@@ -1359,4 +1359,23 @@ int mcpt_debug_fmath(mcpt_scene *sc, int kind, int64_t n, const float *x, const 
     return MCPT_OK;
 }
 
+int mcpt_debug_material(mcpt_scene *sc, int kind, int64_t n, const float *in, const int32_t *sel, float *out) {
+    if (!sc || kind < 0 || kind > 6 || n < 0 || (n > 0 && (!in || !sel || !out))) return fail(MCPT_ERR_ARG, "mcpt_debug_material: bad argument");
+    if (n == 0) return MCPT_OK;
+    if (n > 0x0fffffff) return fail(MCPT_ERR_ARG, "mcpt_debug_material: too many rows for one call");
+    for (int64_t i = 0; i < n; ++i)
+        if (sel[3 * i] < 0 || (size_t)sel[3 * i] >= sc->mats.bytes() / sizeof(MaterialRec) || sel[3 * i + 1] < 0 || sel[3 * i + 1] > 2) return fail(MCPT_ERR_ARG, "mcpt_debug_material: material or channel out of range");
+    HIP_TRY(hipSetDevice(sc->device));
+    DevBuf<float> dI, dO;
+    DevBuf<int32_t> dS;
+    HIP_TRY(dI.alloc((size_t)n * 13));
+    HIP_TRY(dS.alloc((size_t)n * 3));
+    HIP_TRY(dO.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpy(dI.p, in, (size_t)n * 13 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dS.p, sel, (size_t)n * 3 * sizeof(int32_t), hipMemcpyHostToDevice));
+    launch_debug_material(sc->view, kind, (uint32_t)n, dI.p, dS.p, dO.p, nullptr);
+    HIP_TRY(hipMemcpy(out, dO.p, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
 }  // extern "C"

@@ -1296,6 +1296,44 @@ __global__ __launch_bounds__(kBlock) void k_debug_fmath(int kind, uint32_t n, co
     }
 }
 
+// Material functions on arrays (mcpt_debug_material): rows of `in` are {a.xyz, b.xyz, c.xyz, uv.xy, u1, u2}, `sel` = {material, channel,
+// is_reflect}; out = 4 floats per row.  kind 0 eval(wi=a, wo=b, n=c), 1 pdf, 2 fresnel(I=a, N=b), 3 sample(n=a, u1, u2), 4 refract(I=a, N=b),
+// 5 the fused eval+pdf of k_shade (out = {eval, pdf}), 6 reflect(I=a, N=b).
+__global__ __launch_bounds__(kBlock) void k_debug_material(DevScene S, int kind, uint32_t n, const float *__restrict__ in, const int32_t *__restrict__ sel,
+                                                           float *__restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float *r = in + (size_t)i * 13;
+    const f3 a = mk3(r[0], r[1], r[2]), b = mk3(r[3], r[4], r[5]), c = mk3(r[6], r[7], r[8]);
+    const f2 uv{r[9], r[10]};
+    const MaterialRec m = S.mats[sel[3 * i]];
+    const int ch = sel[3 * i + 1];
+    const bool refl = sel[3 * i + 2] != 0;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    switch (kind) {
+    case 0: o[0] = mat_eval(m, a, b, c, ch, uv, refl); break;
+    case 1: o[0] = mat_pdf(m, a, b, c, ch, refl); break;
+    case 2: o[0] = mat_fresnel(m, a, b, ch); break;
+    case 3: {
+        const f3 v = mat_sample(m, a, r[11], r[12]);
+        o[0] = v.x, o[1] = v.y, o[2] = v.z;
+        break;
+    }
+    case 4: {
+        const f3 v = mat_refract(m, a, b, ch);
+        o[0] = v.x, o[1] = v.y, o[2] = v.z;
+        break;
+    }
+    case 5: mat_eval_pdf_rough(m, a, b, c, ch, uv, refl, o[0], o[1]); break;
+    default: {
+        const f3 v = mat_reflect(a, b);
+        o[0] = v.x, o[1] = v.y, o[2] = v.z;
+        break;
+    }
+    }
+    for (int k = 0; k < 4; ++k) out[(size_t)i * 4 + k] = o[k];
+}
+
 // Renderer.cpp:95-103 on the device: one lane per pixel, RGBA8 out (alpha 255).
 __global__ __launch_bounds__(kBlock) void k_tonemap(const float *__restrict__ fb, uint32_t n_pix, uchar4 *__restrict__ rgba) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -1448,6 +1486,11 @@ void launch_add_frame(float *a, const float *b, uint32_t n, hipStream_t s) {
 void launch_debug_fmath(int kind, uint32_t n, const float *x, const float *y, float *out, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_debug_fmath, dim3(blocks(n)), dim3(kBlock), 0, s, kind, n, x, y, out);
+}
+
+void launch_debug_material(const DevScene &S, int kind, uint32_t n, const float *in, const int32_t *sel, float *out, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_debug_material, dim3(blocks(n)), dim3(kBlock), 0, s, S, kind, n, in, sel, out);
 }
 
 void launch_accumulate(const float *result, const uint32_t *pixel_list, uint32_t n_pix, int32_t s_pass, float spp_total,

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MCPT_LIB") or os.path.join(HERE, "libmcpt_hip.so")  #
 CHECK_LIB_PATH = os.path.join(HERE, "libmcpt_hip_check.so")  # the checking build (build.build_check); tests only
 
 EXPORTS = ["mcpt_scene_create", "mcpt_scene_destroy", "mcpt_render", "mcpt_render_device", "mcpt_intersect",
-           "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_bvh_dump", "mcpt_scene_create_ex", "mcpt_scene_dump_bvh", "mcpt_tonemap", "mcpt_tonemap_device", "mcpt_debug_fmath", "mcpt_debug_counters",
+           "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_bvh_dump", "mcpt_scene_create_ex", "mcpt_scene_dump_bvh", "mcpt_tonemap", "mcpt_tonemap_device", "mcpt_debug_fmath", "mcpt_debug_material", "mcpt_debug_counters",
            "mcpt_group_create", "mcpt_group_render", "mcpt_group_size", "mcpt_group_destroy", "mcpt_group_last_error",
            "mcpt_last_error", "mcpt_version"]
 
@@ -106,6 +106,8 @@ def lib(path=None):
         L.mcpt_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64] + [C.c_void_p] * 4
         L.mcpt_debug_fmath.restype = C.c_int
         L.mcpt_debug_fmath.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcpt_debug_material.restype = C.c_int
+        L.mcpt_debug_material.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcpt_group_create.restype = C.c_int
         L.mcpt_group_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.mcpt_group_render.restype = C.c_int
@@ -261,6 +263,17 @@ class HipScene:
         _check(self.L.mcpt_render_device(self.h, _ptr(cam), C.byref(p), C.c_void_p(int(fb_ptr)), C.c_void_p(int(stream_ptr)),
                                          C.byref(st)), L=self.L)
         return st
+
+    MATERIAL_KINDS = {"eval": 0, "pdf": 1, "fresnel": 2, "sample": 3, "refract": 4, "eval_pdf": 5, "reflect": 6}
+
+    def debug_material(self, kind, rows, sel):
+        """The device's Material functions on arrays (mcpt_debug_material): rows [n, 13] = {a, b, c, uv, u1, u2}, sel [n, 3] =
+        {material index, channel, is_reflect}; returns [n, 4]."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, 13)
+        sel = np.ascontiguousarray(sel, dtype=np.int32).reshape(-1, 3)
+        out = np.zeros((len(rows), 4), np.float32)
+        _check(self.L.mcpt_debug_material(self.h, self.MATERIAL_KINDS[kind], len(rows), _ptr(rows), _ptr(sel), _ptr(out)), L=self.L)
+        return out
 
     def intersect(self, origins, dirs):
         o = np.ascontiguousarray(origins, dtype=np.float32)

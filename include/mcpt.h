@@ -238,6 +238,13 @@ int mcpt_scene_dump_bvh(mcpt_scene *scene, mcpt_bvh_info *info, float *boxes, in
  * y may be NULL unless kind is 2 or 4. */
 int mcpt_debug_fmath(mcpt_scene *scene, int kind, int64_t n, const float *x, const float *y, float *out);
 
+/* Diagnostic: evaluates the device's Material functions (csrc/mcpt_device.h, following Material.hpp:26-151,178-408) for n rows, so
+ * that tests can compare them one by one -- not only through whole paths -- with the CPU restatement.  in: 13 floats per row
+ * {a.xyz, b.xyz, c.xyz, uv.xy, u1, u2}; sel: 3 ints per row {material index, channel 0..2, is_reflect}; out: 4 floats per row.
+ * kind 0 Material::eval(wi = a, wo = b, N = c, uv), 1 Material::pdf(a, b, c), 2 fresnel(I = a, N = b), 3 sample(N = a; u1, u2) -> xyz,
+ * 4 refract(I = a, N = b) -> xyz, 5 the fused eval + pdf of the shading kernel -> {eval, pdf}, 6 reflect(I = a, N = b) -> xyz. */
+int mcpt_debug_material(mcpt_scene *scene, int kind, int64_t n, const float *in, const int32_t *sel, float *out);
+
 /* Diagnostic: counters of the checking build (libmcpt_hip_check.so, compiled with -DMCPT_CHECK_DIRECT_SKIP; the traversal
  * entries are filled only by a -DMCPT_TRAVERSAL_STATS build); all zero in the product build.
  *   out[0..5]   closest-hit rays: rays, node visits, primitive tests, hits, 64 x wave iterations, -
