@@ -1378,4 +1378,19 @@ int mcpt_debug_material(mcpt_scene *sc, int kind, int64_t n, const float *in, co
     return MCPT_OK;
 }
 
+int mcpt_debug_scene(mcpt_scene *sc, int kind, int64_t n, const float *in, float *out) {
+    if (!sc || kind < 0 || kind > 1 || n < 0 || (n > 0 && (!in || !out))) return fail(MCPT_ERR_ARG, "mcpt_debug_scene: bad argument");
+    if (n == 0) return MCPT_OK;
+    if (n > 0x0fffffff) return fail(MCPT_ERR_ARG, "mcpt_debug_scene: too many rows for one call");
+    const size_t n_in = kind == 0 ? 4 : 3, n_out = kind == 0 ? 10 : 3;
+    HIP_TRY(hipSetDevice(sc->device));
+    DevBuf<float> dI, dO;
+    HIP_TRY(dI.alloc((size_t)n * n_in));
+    HIP_TRY(dO.alloc((size_t)n * n_out));
+    HIP_TRY(hipMemcpy(dI.p, in, (size_t)n * n_in * sizeof(float), hipMemcpyHostToDevice));
+    launch_debug_scene(sc->view, kind, (uint32_t)n, dI.p, dO.p, nullptr);
+    HIP_TRY(hipMemcpy(out, dO.p, (size_t)n * n_out * sizeof(float), hipMemcpyDeviceToHost));
+    return MCPT_OK;
+}
+
 }  // extern "C"

@@ -141,6 +141,7 @@ void launch_add_frame(float *a, const float *b, uint32_t n, hipStream_t s);
 // Tone map of Renderer.cpp:95-103: n_pix RGB float triples -> n_pix RGBA8 (csrc/mcpt_fmath.h: mcpt_tonemap_byte).
 void launch_tonemap(const float *fb, uint32_t n_pix, unsigned char *rgba, hipStream_t s);
 void launch_debug_fmath(int kind, uint32_t n, const float *x, const float *y, float *out, hipStream_t s);
+void launch_debug_scene(const DevScene &S, int kind, uint32_t n, const float *in, float *out, hipStream_t s);
 void launch_debug_material(const DevScene &S, int kind, uint32_t n, const float *in, const int32_t *sel, float *out, hipStream_t s);
 void launch_accumulate(const float *result, const uint32_t *pixel_list, uint32_t n_pix, int32_t s_pass, float spp_total,
                        float *fb, hipStream_t s);

@@ -1334,6 +1334,25 @@ __global__ __launch_bounds__(kBlock) void k_debug_material(DevScene S, int kind,
     for (int k = 0; k < 4; ++k) out[(size_t)i * 4 + k] = o[k];
 }
 
+// Scene functions on arrays (mcpt_debug_scene): kind 0 Scene::sampleLight for 4 uniforms per row -> {x_l, n_l, emit, pdf} (10 floats; zeros
+// when no light was selected), kind 1 Scene::sampleEnv for a direction per row -> rgb.
+__global__ __launch_bounds__(kBlock) void k_debug_scene(DevScene S, int kind, uint32_t n, const float *__restrict__ in, float *__restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (kind == 0) {
+        const float u[4] = {in[4 * i], in[4 * i + 1], in[4 * i + 2], in[4 * i + 3]};
+        f3 x = mk3(0, 0, 0), nl = mk3(0, 0, 0), e = mk3(0, 0, 0);
+        float pdf = 0.f;
+        int32_t prim = -1;
+        (void)sample_light(S, u, x, nl, e, pdf, prim);
+        float *o = out + (size_t)i * 10;
+        o[0] = x.x, o[1] = x.y, o[2] = x.z, o[3] = nl.x, o[4] = nl.y, o[5] = nl.z, o[6] = e.x, o[7] = e.y, o[8] = e.z, o[9] = pdf;
+    } else {
+        const f3 c = sample_env(S, mk3(in[3 * i], in[3 * i + 1], in[3 * i + 2]));
+        out[3 * i] = c.x, out[3 * i + 1] = c.y, out[3 * i + 2] = c.z;
+    }
+}
+
 // Renderer.cpp:95-103 on the device: one lane per pixel, RGBA8 out (alpha 255).
 __global__ __launch_bounds__(kBlock) void k_tonemap(const float *__restrict__ fb, uint32_t n_pix, uchar4 *__restrict__ rgba) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -1486,6 +1505,11 @@ void launch_add_frame(float *a, const float *b, uint32_t n, hipStream_t s) {
 void launch_debug_fmath(int kind, uint32_t n, const float *x, const float *y, float *out, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_debug_fmath, dim3(blocks(n)), dim3(kBlock), 0, s, kind, n, x, y, out);
+}
+
+void launch_debug_scene(const DevScene &S, int kind, uint32_t n, const float *in, float *out, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_debug_scene, dim3(blocks(n)), dim3(kBlock), 0, s, S, kind, n, in, out);
 }
 
 void launch_debug_material(const DevScene &S, int kind, uint32_t n, const float *in, const int32_t *sel, float *out, hipStream_t s) {

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MCPT_LIB") or os.path.join(HERE, "libmcpt_hip.so")  #
 CHECK_LIB_PATH = os.path.join(HERE, "libmcpt_hip_check.so")  # the checking build (build.build_check); tests only
 
 EXPORTS = ["mcpt_scene_create", "mcpt_scene_destroy", "mcpt_render", "mcpt_render_device", "mcpt_intersect",
-           "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_bvh_dump", "mcpt_scene_create_ex", "mcpt_scene_dump_bvh", "mcpt_tonemap", "mcpt_tonemap_device", "mcpt_debug_fmath", "mcpt_debug_material", "mcpt_debug_counters",
+           "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_bvh_dump", "mcpt_scene_create_ex", "mcpt_scene_dump_bvh", "mcpt_tonemap", "mcpt_tonemap_device", "mcpt_debug_fmath", "mcpt_debug_material", "mcpt_debug_scene", "mcpt_debug_counters",
            "mcpt_group_create", "mcpt_group_render", "mcpt_group_size", "mcpt_group_destroy", "mcpt_group_last_error",
            "mcpt_last_error", "mcpt_version"]
 
@@ -106,6 +106,8 @@ def lib(path=None):
         L.mcpt_camera_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int64] + [C.c_void_p] * 4
         L.mcpt_debug_fmath.restype = C.c_int
         L.mcpt_debug_fmath.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcpt_debug_scene.restype = C.c_int
+        L.mcpt_debug_scene.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         L.mcpt_debug_material.restype = C.c_int
         L.mcpt_debug_material.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcpt_group_create.restype = C.c_int
@@ -273,6 +275,20 @@ class HipScene:
         sel = np.ascontiguousarray(sel, dtype=np.int32).reshape(-1, 3)
         out = np.zeros((len(rows), 4), np.float32)
         _check(self.L.mcpt_debug_material(self.h, self.MATERIAL_KINDS[kind], len(rows), _ptr(rows), _ptr(sel), _ptr(out)), L=self.L)
+        return out
+
+    def sample_light(self, u):
+        """The device's Scene::sampleLight for rows of four uniforms (mcpt_debug_scene) -> [n, 10] = {point, normal, emission, pdf}."""
+        u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, 4)
+        out = np.zeros((len(u), 10), np.float32)
+        _check(self.L.mcpt_debug_scene(self.h, 0, len(u), _ptr(u), _ptr(out)), L=self.L)
+        return out
+
+    def sample_env(self, dirs):
+        """The device's Scene::sampleEnv for rows of directions -> [n, 3]."""
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((len(d), 3), np.float32)
+        _check(self.L.mcpt_debug_scene(self.h, 1, len(d), _ptr(d), _ptr(out)), L=self.L)
         return out
 
     def intersect(self, origins, dirs):

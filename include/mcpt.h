@@ -245,6 +245,11 @@ int mcpt_debug_fmath(mcpt_scene *scene, int kind, int64_t n, const float *x, con
  * 4 refract(I = a, N = b) -> xyz, 5 the fused eval + pdf of the shading kernel -> {eval, pdf}, 6 reflect(I = a, N = b) -> xyz. */
 int mcpt_debug_material(mcpt_scene *scene, int kind, int64_t n, const float *in, const int32_t *sel, float *out);
 
+/* Diagnostic: the device's Scene::sampleLight (Scene.cpp:23-37 with MeshTriangle::Sample, BVHAccel::getSample, Triangle::Sample; kind 0:
+ * in = 4 uniforms per row {light choice, triangle pick, x, y}, out = 10 floats per row {point, normal, emission, pdf}) and
+ * Scene::sampleEnv (Scene.hpp:60-99; kind 1: in = a direction per row, out = rgb) on arrays. */
+int mcpt_debug_scene(mcpt_scene *scene, int kind, int64_t n, const float *in, float *out);
+
 /* Diagnostic: counters of the checking build (libmcpt_hip_check.so, compiled with -DMCPT_CHECK_DIRECT_SKIP; the traversal
  * entries are filled only by a -DMCPT_TRAVERSAL_STATS build); all zero in the product build.
  *   out[0..5]   closest-hit rays: rays, node visits, primitive tests, hits, 64 x wave iterations, -

@@ -1083,6 +1083,27 @@ void orc_material_refract(const orc_material *sm, const float *I, const float *N
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 
+/* Scene::sampleLight (Scene.cpp:23-37) and Scene::sampleEnv (Scene.hpp:60-99) on arrays, for the device-vs-oracle function tests:
+ * kind 0: u = 4 floats per row {light choice, triangle pick, x, y} -> out 10 floats {coords, normal, emit, pdf};
+ * kind 1: in = 3 floats per row (a direction) -> out 3 floats (radiance). */
+void orc_scene_function(const orc_scene *s, int kind, int64_t n, const float *in, float *out) {
+    for (int64_t i = 0; i < n; ++i) {
+        if (kind == 0) {
+            intersection pos = no_hit();
+            float pdf = 0.f;
+            scene_sample_light(s, in + 4 * i, &pos, &pdf);
+            float *o = out + 10 * i;
+            o[0] = pos.coords.x; o[1] = pos.coords.y; o[2] = pos.coords.z;
+            o[3] = pos.normal.x; o[4] = pos.normal.y; o[5] = pos.normal.z;
+            o[6] = pos.emit.x; o[7] = pos.emit.y; o[8] = pos.emit.z;
+            o[9] = pdf;
+        } else {
+            v3 c = scene_sample_env(s, ld3(in + 3 * i));
+            out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+        }
+    }
+}
+
 /* mcpt_fmath.h entry points for tests/test_fmath.py: kind 0 sin, 1 cos, 2 atan2(x, y), 3 acos, 4 pow(x, y), 5 tone-map byte */
 void orc_fmath(int kind, int64_t n, const float *x, const float *y, float *out) {
     for (int64_t i = 0; i < n; ++i) {

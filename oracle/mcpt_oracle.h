@@ -119,6 +119,10 @@ float orc_material_fresnel(const orc_material *m, const float *I, const float *N
 void orc_material_sample(const orc_material *m, const float *n, float u1, float u2, float *out);
 void orc_material_refract(const orc_material *m, const float *I, const float *N, int channel, float *out);
 
+/* Scene::sampleLight (kind 0: 4 uniforms per row -> {coords, normal, emit, pdf}, 10 floats) and Scene::sampleEnv (kind 1: a direction
+ * per row -> rgb) on arrays. */
+void orc_scene_function(const orc_scene *s, int kind, int64_t n, const float *in, float *out);
+
 /* Philox4x32-10 (Salmon et al. 2011), for KAT tests. */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

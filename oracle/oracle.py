@@ -69,6 +69,7 @@ def lib():
         L.orc_philox4x32_10.argtypes = [C.c_void_p] * 3
         L.orc_tonemap.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.orc_fmath.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_scene_function.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -102,6 +103,20 @@ class OracleScene:
         if rc != 0:
             raise RuntimeError("orc_scene_create failed: %d" % rc)
         self.h = h
+
+    def sample_light(self, u):
+        """Scene::sampleLight for rows of four uniforms -> [n, 10] = {coords, normal, emit, pdf}."""
+        u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, 4)
+        out = np.zeros((len(u), 10), np.float32)
+        lib().orc_scene_function(self.h, 0, len(u), _ptr(u), _ptr(out))
+        return out
+
+    def sample_env(self, dirs):
+        """Scene::sampleEnv for rows of directions -> [n, 3]."""
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((len(d), 3), np.float32)
+        lib().orc_scene_function(self.h, 1, len(d), _ptr(d), _ptr(out))
+        return out
 
     def close(self):
         if getattr(self, "h", None):

@@ -82,3 +82,59 @@ def test_material_functions_bit_identical_to_the_oracle(pkg, oracle, hip, scene)
     want = (N * (np.float32(2) * d)[:, None]).astype(np.float32) - I
     assert _same(want, gpu["reflect"][:, :3]).all()
     assert np.isfinite(gpu["eval"][:, 0]).mean() > 0.9 and (gpu["eval"][:, 0] != 0).mean() > 0.05  # (the inputs reach the non-trivial branches)
+
+
+def _quad(pkg, a, b, c, d):
+    t = np.zeros(2, pkg.scenes.TRI_DTYPE)
+    t["v0"], t["v1"], t["v2"] = [a, a], [b, c], [c, d]
+    return t
+
+
+def _many_lights(pkg):
+    """Three emitters in insertion order -- a 1 x 1 quad, a sphere, a 3 x 2 fan of 12 triangles -- so that the light choice
+    (Scene.cpp:28-36), the area walk of a mesh's tree (BVH.cpp:118-129) and Sphere::Sample all have something to choose from."""
+    s = pkg.scenes
+    P = s.material_presets()
+    b = s._Builder()
+    b.add_mesh(_quad(pkg, (-0.5, 2, -0.5), (0.5, 2, -0.5), (0.5, 2, 0.5), (-0.5, 2, 0.5)), b.material("l1", s._mat(s.ROUGH_CONDUCTOR, emission=(40, 35, 30))))
+    b.add_sphere((2.0, 1.5, 0.0), 0.3, b.material("l2", s._mat(s.ROUGH_CONDUCTOR, emission=(5, 6, 7))))
+    fan = np.zeros(12, s.TRI_DTYPE)
+    for k in range(12):
+        a0, a1 = 2 * np.pi * k / 12, 2 * np.pi * (k + 1) / 12
+        fan["v0"][k], fan["v1"][k], fan["v2"][k] = (-3, 1, 0), (-3 + 1.5 * np.cos(a0), 1 + np.sin(a0), 0.1 * k), (-3 + 1.5 * np.cos(a1), 1 + np.sin(a1), 0.1 * k)
+    b.add_mesh(fan, b.material("l3", s._mat(s.ROUGH_CONDUCTOR, emission=(1, 2, 3))))
+    b.add_mesh(_quad(pkg, (-6, 0, -6), (-6, 0, 6), (6, 0, 6), (6, 0, -6)), b.material("floor", P["rough_white_conductor"]))
+    cam = s.make_camera(32, 32, 55, (0.3, 1.3, -4.5), (0.2, 1.1, 0.0))
+    return b.finish(background=np.float32([0.05, 0.05, 0.08]), camera=cam, rr_rate=0.8, spp=1, name="many_lights")
+
+
+@pytest.mark.parametrize("scene", ["cornell_demo", "chess", "many_lights"])
+def test_sample_light_bit_identical_to_the_oracle(pkg, oracle, hip, scene):
+    sd = {"cornell_demo": lambda: pkg.scenes.cornell_demo(16, 16, 1), "chess": lambda: pkg.scenes.chess_scene(width=16, height=9, spp=1),
+          "many_lights": lambda: _many_lights(pkg)}[scene]()
+    rng = np.random.default_rng(5)
+    u = (rng.integers(0, 1 << 24, size=(60000, 4)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)  # the path's uniforms
+    u[:64] = rng.choice(np.float32([0.0, 1.0 - 2.0 ** -24, 0.5, 0.25]), size=(64, 4))
+    ref = oracle.OracleScene(sd).sample_light(u)
+    gpu = hip.HipScene(sd).sample_light(u)
+    if scene == "many_lights":
+        # Sphere::Sample leaves Intersection::emit as it was (Sphere.hpp:64-74); both sides start from zero
+        assert len(np.unique(ref[:, 9])) == 3  # all three emitters were chosen (pdf = 1 / area of the chosen one)
+    assert _same(ref, gpu).all(), int((~_same(ref, gpu)).sum())
+
+
+def test_sample_env_bit_identical_to_the_oracle(pkg, oracle, hip):
+    sd = pkg.scenes.cornell_rc(16, 16, 1)
+    rng = np.random.default_rng(6)
+    sd.env_pixels = rng.random((37, 64, 3)).astype(np.float32)
+    d = _unit(rng.normal(size=(60000, 3)))
+    d[:6] = [[0, 1, 0], [0, -1, 0], [1, 0, 0], [-1, 0, 0], [0, 0, 1], [0, 0, -1]]  # poles and the seam of the map
+    d[6:3000, 1] = 0
+    d[6:3000] = _unit(d[6:3000])
+    d[3000:6000] *= rng.uniform(0.1, 9.0, (3000, 1)).astype(np.float32)            # (sampleEnv normalises its argument)
+    ref = oracle.OracleScene(sd).sample_env(d)
+    gpu = hip.HipScene(sd).sample_env(d)
+    assert _same(ref, gpu).all(), int((~_same(ref, gpu)).sum())
+    assert len(np.unique(ref[:, 0])) > 50000
+    sd.env_pixels = None  # the constant background (Scene.hpp:61-63)
+    assert np.array_equal(hip.HipScene(sd).sample_env(d[:10]), oracle.OracleScene(sd).sample_env(d[:10]))
