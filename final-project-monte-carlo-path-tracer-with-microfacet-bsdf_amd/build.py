@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmcpt_hip.so")
 # The checking build: the same sources with the direct-lighting-skip check and the pure test hooks (MCPT_RING_START,
 # MCPT_HOST_DELAY_US) compiled in, and the retry flavour of the traversal stack forced for every tree with only 4 LDS
-# entries (so that most rays lose an entry and are traced again with the scratch stack).  Tests load it explicitly; the product library carries none of it.
+# entries (so that most rays lose an entry, go through the retrace lists and are traced again with the scratch stack).  Tests load it explicitly; the product library carries none of it.
 LIB_CHECK = os.path.join(HERE, "libmcpt_hip_check.so")
 CHECK_DEFINES = ["-DMCPT_TEST_HOOKS", "-DMCPT_CHECK_DIRECT_SKIP", "-DMCPT_FORCE_RETRY", "-DMCPT_STK_RETRY=4"]
 SOURCES = ["mcpt_scene.cpp", "mcpt_kernels.hip", "mcpt_api.hip", "mcpt_multi.hip", "mcpt_lbvh.hip", "mcpt_cull.hip"]

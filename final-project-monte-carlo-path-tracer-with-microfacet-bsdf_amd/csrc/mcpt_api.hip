@@ -84,8 +84,32 @@ struct WaveBufs {
     }
 };
 
+// The retrace lists of the traversal kernels (RetryList, csrc/mcpt_kernels.h): allocated only for scenes whose tree runs the retry
+// flavour of the traversal stack (stack_uses_retry); each list holds as many entries as one launch can have rays.
+struct RetryBufs {
+    DevBuf<uint32_t> ctl;  // {count, done} x 3, zero between launches
+    DevBuf<uint32_t> items[3];
+    uint32_t cap[3] = {0, 0, 0};
+    hipError_t alloc(const uint32_t want[3]) {
+        hipError_t e = ctl.alloc(8);
+        if (e != hipSuccess) return e;
+        if ((e = hipMemset(ctl.p, 0, 8 * sizeof(uint32_t))) != hipSuccess) return e;
+        for (int k = 0; k < 3; ++k) {
+            if ((e = items[k].alloc(want[k])) != hipSuccess) return e;
+            cap[k] = want[k];
+        }
+        return hipSuccess;
+    }
+    RetryList list(int k) const { return ctl.p ? RetryList{ctl.p + 2 * k, ctl.p + 2 * k + 1, items[k].p, cap[k]} : RetryList{nullptr, nullptr, nullptr, 0u}; }
+    void release() {
+        ctl.release();
+        for (int k = 0; k < 3; ++k) items[k].release();
+    }
+};
+
 struct Workspace {
     uint32_t pool = 0, free_ring = 0, ray_cap = 0;
+    RetryBufs retry;  // 0 closest-hit rays, 1 shadow rays, 2 primary samples
     int32_t n_dir = 0, max_depth = 0;
     WaveBufs wave[2];
     DevBuf<float4> vtx0, vtx1, vtx2, shq_o, shq_d;
@@ -99,6 +123,7 @@ struct Workspace {
         wave[0].release(); wave[1].release(); stack.release(); free_slots.release();
         vtx0.release(); vtx1.release(); vtx2.release(); vtx_j.release(); shq_o.release(); shq_d.release();
         counters.release();
+        retry.release();
         if (h_counters) (void)hipHostFree(h_counters);
         h_counters = nullptr;
         pool = 0;
@@ -261,7 +286,7 @@ using PoolCtx = mcpt_scene::PoolCtx;
 
 namespace {
 
-hipError_t ensure_workspace(PoolCtx &ctx, uint32_t pool, int32_t n_dir, int32_t max_depth) {
+hipError_t ensure_workspace(PoolCtx &ctx, uint32_t pool, int32_t n_dir, int32_t max_depth, bool retry_lists) {
     Workspace &w = ctx.ws;
     hipError_t e;
     const size_t n_rays = (size_t)pool + pool / 3 + 64;
@@ -290,6 +315,10 @@ hipError_t ensure_workspace(PoolCtx &ctx, uint32_t pool, int32_t n_dir, int32_t 
     if ((e = w.free_slots.alloc(ring)) != hipSuccess) return e;
     w.free_ring = (uint32_t)ring;
     w.ray_cap = (uint32_t)n_rays;
+    if (retry_lists) {
+        const uint32_t want[3] = {(uint32_t)n_rays, (uint32_t)std::min<uint64_t>((uint64_t)pool * n_dir, 0xffffffffull), pool / 3 + 64};
+        if ((e = w.retry.alloc(want)) != hipSuccess) return e;
+    }
     if ((e = w.counters.alloc(1)) != hipSuccess) return e;
     if (!w.h_counters && (e = hipHostMalloc((void **)&w.h_counters, sizeof(Counters))) != hipSuccess) return e;
     w.pool = pool;
@@ -417,7 +446,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             const uint32_t g = std::min<uint32_t>(room, plan[issue_pass].n_work - issued);
             if (g > 0) {
                 int ev = T.begin(s_prim);
-                launch_primary(sc->view, *cam, C, nx, nxt, issue_pass & 1, plan[issue_pass].first_work + issued, g, s_prim);
+                launch_primary(sc->view, *cam, C, nx, nxt, issue_pass & 1, plan[issue_pass].first_work + issued, g, w.retry.list(2), s_prim);
                 T.end(ev, K_GENERATE, s_prim);
                 tot.closest += g;
             }
@@ -457,7 +486,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             issue_pass = P;
             n_cur_max = n_work;
             int ev = T.begin(st);
-            launch_trace_closest(sc->view, n_work, nullptr, nx.ray_o, nx.ray_d, nx.hit, st);
+            launch_trace_closest(sc->view, n_work, nullptr, nx.ray_o, nx.ray_d, nx.hit, w.retry.list(0), st);
             T.end(ev, K_CLOSEST, st);
             tot.closest += n_work;
         }
@@ -491,11 +520,11 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
                 T.end(ev, K_DIRECT, st);
                 if (C.enable_shadow) {
                     ev = T.begin(st);
-                    launch_trace_shadow(sc->view, w.counters.p, nxt, n_cur_max * (uint32_t)n_dir, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, K.shadow_grid_per_cu, st);
+                    launch_trace_shadow(sc->view, w.counters.p, nxt, n_cur_max * (uint32_t)n_dir, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, K.shadow_grid_per_cu, w.retry.list(1), st);
                     T.end(ev, K_SHADOW, st);
                 }
                 ev = T.begin(st);
-                launch_trace_closest(sc->view, n_cur_max, &w.counters.p->n_rays[nxt].v, nx.ray_o, nx.ray_d, nx.hit, st);
+                launch_trace_closest(sc->view, n_cur_max, &w.counters.p->n_rays[nxt].v, nx.ray_o, nx.ray_d, nx.hit, w.retry.list(0), st);
                 T.end(ev, K_CLOSEST, st);
                 cur = nxt;
             }
@@ -558,7 +587,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
         if (grid_cont > 0) {
             if (ctx.side[0]) HIP_TRY(hipStreamWaitEvent(s_close, ctx.shaded, 0));
             ev = T.begin(s_close);
-            launch_trace_closest(sc->view, grid_cont, queue_ahead ? &w.counters.p->n_rays[nxt].v : nullptr, nx.ray_o, nx.ray_d, nx.hit, s_close);
+            launch_trace_closest(sc->view, grid_cont, queue_ahead ? &w.counters.p->n_rays[nxt].v : nullptr, nx.ray_o, nx.ray_d, nx.hit, w.retry.list(0), s_close);
             T.end(ev, K_CLOSEST, s_close);
         }
         launch_bookkeep(w.counters.p, cur, false, 0, 0, 0, st);  // totals += lengths; list `cur` is consumed
@@ -569,7 +598,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             T.end(ev, K_DIRECT, st);
             if (C.enable_shadow) {
                 ev = T.begin(st);
-                launch_trace_shadow(sc->view, w.counters.p, nxt, grid_direct * (uint32_t)n_dir, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, K.shadow_grid_per_cu, st);
+                launch_trace_shadow(sc->view, w.counters.p, nxt, grid_direct * (uint32_t)n_dir, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, K.shadow_grid_per_cu, w.retry.list(1), st);
                 T.end(ev, K_SHADOW, st);
             }
         }
@@ -627,7 +656,8 @@ uint64_t bytes_per_pool_path(int n_dir, int max_depth) {
     const double rays = 1.0 + 1.0 / 3.0;
     const double wave = 16 + 16 + rays * 48 + 4.0 * n_dir + 8.0 / 3.0;
     const double scratch = 3 * 16 + 4 + 32.0 * n_dir;
-    return (uint64_t)(2 * wave + scratch + 16.0 * max_depth + 16.0);
+    const double retrace = 4.0 * (rays + n_dir + 1.0 / 3.0);  // (lists of the retry flavour; counted whether or not the tree needs them)
+    return (uint64_t)(2 * wave + scratch + retrace + 16.0 * max_depth + 16.0);
 }
 
 int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, float *fb_dev, hipStream_t st,
@@ -720,7 +750,7 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
         return MCPT_OK;
     }
     // (n_pix == 0 with owned pixels: every one of them was culled; the loop below then has no samples to issue and falls through)
-    for (int k = 0; k < n_pools; ++k) HIP_TRY(ensure_workspace(sc->pools[k], pool, p.n_dir_sample, max_depth));
+    for (int k = 0; k < n_pools; ++k) HIP_TRY(ensure_workspace(sc->pools[k], pool, p.n_dir_sample, max_depth, stack_uses_retry(sc->view.height)));
     // two halves: a pass accumulates from one while the next pass fills the other (one half with a single pass)
     const size_t half_floats = (size_t)n_pix * s_pass * 3;
     const bool two_halves = n_pools == 1 && p.spp > s_pass;
@@ -1208,7 +1238,12 @@ int mcpt_intersect(mcpt_scene *sc, int64_t n, const float *origins, const float 
     HIP_TRY(upload(dO, o));
     HIP_TRY(upload(dD, d));
     HIP_TRY(dH.alloc(n));
-    launch_trace_closest(sc->view, (uint32_t)n, nullptr, dO.p, dD.p, dH.p, nullptr);
+    RetryBufs retry;
+    if (stack_uses_retry(sc->view.height)) {
+        const uint32_t want[3] = {(uint32_t)n, 1u, 1u};
+        HIP_TRY(retry.alloc(want));
+    }
+    launch_trace_closest(sc->view, (uint32_t)n, nullptr, dO.p, dD.p, dH.p, retry.list(0), nullptr);
     std::vector<uint4> h(n);
     const hipError_t e = hipMemcpy(h.data(), dH.p, n * sizeof(uint4), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(MCPT_ERR_HIP, std::string("mcpt_intersect: ") + hipGetErrorString(e));
@@ -1242,7 +1277,7 @@ int mcpt_cast_rays(mcpt_scene *sc, const mcpt_params *pp, int64_t n, const float
     for (int64_t base = 0; base < n; base += chunk_max) {
         const uint32_t m = (uint32_t)std::min<int64_t>(chunk_max, n - base);
         const uint32_t pool = std::max<uint32_t>((m + 2) / 3 * 3, 3 * 256);
-        HIP_TRY(ensure_workspace(ctx, std::max(pool, w.pool), p.n_dir_sample, std::max(max_depth, w.max_depth)));
+        HIP_TRY(ensure_workspace(ctx, std::max(pool, w.pool), p.n_dir_sample, std::max(max_depth, w.max_depth), stack_uses_retry(sc->view.height)));
         HIP_TRY(sh.result.alloc(m));
         HIP_TRY(sh.key_pixel.alloc(m));
         HIP_TRY(sh.key_sample.alloc(m));

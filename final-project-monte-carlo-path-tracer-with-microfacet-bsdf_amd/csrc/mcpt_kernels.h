@@ -98,6 +98,19 @@ struct CameraConst {
     float orient[9];
 };
 
+// Retrace list of one traversal kernel (retry flavour of the traversal stack, MCPT_STK_PUSH in mcpt_kernels.hip): the rays of a launch that
+// lost a stack entry; the retrace kernel launched right behind traces them again with the scratch stack and clears the list.  `cap` is the
+// largest number of rays one launch can hold, so the list cannot overflow.
+struct RetryList {
+    uint32_t *count;  // entries
+    uint32_t *done;   // workgroups of the retrace kernel that have finished (the last one clears both counters)
+    uint32_t *items;  // ray index (closest), queue position (shadow), sample index (primary)
+    uint32_t cap;
+};
+struct RetryLists {
+    RetryList closest, shadow, primary;
+};
+
 // Traversal-stack entries per lane the traversal kernels provide for a tree of this height (a ray holds at most one child reference
 // per inner ancestor, i.e. height - 1).  0: the tree is too deep for any instantiation.
 #ifndef MCPT_STK_B
@@ -105,8 +118,28 @@ struct CameraConst {
 #endif
 constexpr int kStkB = MCPT_STK_B;  // entries for trees of height 18..20.  (19 would be exact for height 20 and lets 8 instead of 7 workgroups of k_primary /
 // k_trace_shadow share a CU: they gain what k_direct beside them loses -- frame rate +1 %, +0.1 %, -0.8 % in three A/B runs: no change.)
+#ifndef MCPT_PLAIN_MAX_HEIGHT
+#define MCPT_PLAIN_MAX_HEIGHT 24
+#endif
+// Deepest tree traversed with an LDS stack that holds every entry (24 entries for 21-24 levels).  Measured on the 296 k-triangle SAH
+// tree (24 levels): 24 LDS entries 3970 Msamples/s, retry flavour 3925 -- its traversal kernels are faster with 8 instead of 6
+// workgroups per CU, but k_direct beside them loses more than they gain.
+constexpr int kPlainMaxHeight = MCPT_PLAIN_MAX_HEIGHT;
+static_assert(kPlainMaxHeight == 20 || kPlainMaxHeight == 24, "plain stack classes: 16, kStkB (<= 20 levels), 24");
+// true: the traversal kernels of a tree of this height run the retry flavour and need their retrace lists (RetryList)
+inline bool stack_uses_retry(int height) {
+#if defined(MCPT_LDS_ONLY_STACKS)
+    (void)height;
+    return false;
+#elif defined(MCPT_FORCE_RETRY)
+    (void)height;
+    return true;
+#else
+    return height > kPlainMaxHeight;
+#endif
+}
 inline int traversal_stack_entries(int height) {
-    return height <= 17 ? 16 : (height <= 20 ? kStkB : (height <= kMaxBvhHeight ? kMaxBvhHeight : 0));  // (deeper than 20: 16 in LDS, and the scratch stack of kMaxBvhHeight entries for rays that need more)
+    return height <= 17 ? 16 : (height <= 20 ? kStkB : (height <= kPlainMaxHeight ? 24 : (height <= kMaxBvhHeight ? kMaxBvhHeight : 0)));  // (deeper: 16 in LDS, and the scratch stack of kMaxBvhHeight entries for the rays that need more)
 }
 
 void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, uint32_t start, uint32_t mask, hipStream_t s);
@@ -117,13 +150,13 @@ void launch_bookkeep(Counters *c, int cur_idx, bool from_host, uint32_t n_next, 
 // three channel results directly; any other hit appends one ray/hit entry and three fresh path records to
 // wave `next` (list index `next_idx`).
 void launch_primary(const DevScene &S, const CameraConst &cam, const RenderConst &C, Wave next, int next_idx, int parity,
-                    uint32_t first_sample, uint32_t n_samples, hipStream_t s);
+                    uint32_t first_sample, uint32_t n_samples, const RetryList &rl, hipStream_t s);
 void launch_generate_explicit(const RenderConst &C, Wave next, int next_idx, uint32_t n, hipStream_t s);
 void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const uint32_t *pixel, const uint32_t *sample,
                         float4 *o, float4 *d, hipStream_t s);
 // n_dev != nullptr: the ray count is read on the device (n then only sizes the grid, which strides over the queue).
 void launch_trace_closest(const DevScene &S, uint32_t n, const uint32_t *n_dev, const float4 *ray_o, const float4 *ray_d, uint4 *hit,
-                          hipStream_t s);
+                          const RetryList &rl, hipStream_t s);
 // Direct lighting (Scene::directLighting, Scene.cpp:56-82) for the n_vertices entries of the k_direct work list:
 // one lane per (vertex, light sample); fills next.contrib and appends the non-zero samples to the shadow queue.  The list
 // length is read on the device; the grid (n_vertices_grid vertices) strides over it.
@@ -131,7 +164,7 @@ void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X
 // Shadow queue (lengths in counters->n_shadow / n_shadow_w, together at most n_max; arrays of `cap` entries): zeroes
 // contrib[] of invisible samples.
 void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, uint32_t cap, Scratch X,
-                         float *contrib, uint32_t grid_per_cu, hipStream_t s);
+                         float *contrib, uint32_t grid_per_cu, const RetryList &rl, hipStream_t s);
 // Shades list `cur_idx` (at most n_cur_max records; the true count is read from the device counter) into the other list.
 void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, Scratch X, int cur_idx, uint32_t n_cur_max,
                   hipStream_t s);

@@ -117,6 +117,7 @@ struct TraceResult {
     int32_t prim;
     uint32_t mat_bits;  // closest hit: material index | emissive << 31
     bool visible;       // shadow queries only
+    bool dropped;       // retry flavour: a stack entry was lost, the result is void (the ray goes to the retrace list)
 };
 
 // One traversal loop, three query kinds:
@@ -145,14 +146,14 @@ struct TraceState {
 // workgroups (up to 19 entries: 8 per CU, 20-22: 7, 23-26: 6, 32: 5, 48: 3).  Three flavours:
 //   plain   trees of up to 24 levels: STK >= height - 1 LDS entries, a push can never fail.
 //   retry   deeper trees (RETRY): 16 LDS entries; a push onto a full stack drops the entry and marks the ray (`dropped`).  The walk goes on
-//           (it only visits less) and its result is thrown away: a marked ray is traced again, from the start, by the
+//           (it only visits less) and its result is thrown away: the ray goes to the kernel's RETRACE LIST (RetryList), and a small
+//           kernel launched right behind (k_retrace_closest / k_retrace_shadow / k_primary_retrace) traces the listed rays again with the
 //   scratch flavour (STK = 0, SCR): the whole stack is a per-lane array of kMaxBvhHeight entries in scratch memory -- slow and exact.
-// Results never depend on the stack size: the checking build (-DMCPT_FORCE_RETRY -DMCPT_STK_RETRY=4) retraces most rays of every
-// scene and renders the same frames (tests/test_gpu_checks.py).  Measured, chess frame with the GPU-built tree (27 levels): 32 LDS
-// entries 3700 Msamples/s, retry flavour 4000 (8 workgroups per CU instead of 5); the second copy of the loop costs registers and
-// instruction cache, though (the same kernels with 16 entries and no retry code: 4280), which is why 21-24-level trees keep their
-// 24 LDS entries (the 296 k-triangle scene: 4090 with 24 entries, 3800 with the retry flavour, 4140 with 16 entries and no retry
-// code).  An overflow array behind the LDS entries inside the hot loop (one compare per pop) measured 4000 on that scene too.
+// The hot kernels carry no second copy of the loop: a retrace inlined behind the first walk was measured first and cost them 6-8 %
+// (registers, scratch set-up, instruction cache); so did an overflow array behind the LDS entries inside the loop (a compare per pop).
+// Results never depend on the stack size: the checking build (-DMCPT_FORCE_RETRY -DMCPT_STK_RETRY=4) sends most rays of every scene
+// through the lists and renders the same frames (tests/test_gpu_checks.py).  Measured, chess frame with the GPU-built tree (27
+// levels): 32 LDS entries 3700 Msamples/s, retry flavour 4160 (8 workgroups per CU instead of 5).
 #ifndef MCPT_STK_RETRY
 #define MCPT_STK_RETRY 16
 #endif
@@ -403,9 +404,6 @@ MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_
     st.nv = st.nt = st.iters = st.maxsp = 0;
 #endif
     MCPT_QUERY(STK, false, RETRY, nullptr);
-    if (RETRY) {
-        if (st.dropped) traverse_again<SHADOW>(S, r, dist, stk, tid, found, st);
-    }
 #ifdef MCPT_TRAVERSAL_STATS
     if (S.dbg) {  // [kind*8 + {rays, node visits, prim tests, occluded/hit, wave-iterations*64, found}]
         const int base = SHADOW ? 8 : 0;
@@ -420,7 +418,34 @@ MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_
         atomicMax(&S.dbg[SHADOW ? 7 : 6], (unsigned long long)st.maxsp);  // deepest stack of any ray (1000: an entry was dropped)
     }
 #endif
-    return TraceResult{st.best_t, st.best_prim, st.best_mat, !st.occluded && st.found};
+    return TraceResult{st.best_t, st.best_prim, st.best_mat, !st.occluded && st.found, RETRY ? st.dropped : false};
+}
+
+// The retrace of one listed ray (scratch flavour).
+template <bool SHADOW>
+MCPT_DI TraceResult traverse_scratch(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, bool found = false) {
+    TraceState st;
+#ifdef MCPT_TRAVERSAL_STATS
+    st.nv = st.nt = st.iters = st.maxsp = 0;
+#endif
+    traverse_again<SHADOW>(S, r, dist, stk, tid, found, st);
+    return TraceResult{st.best_t, st.best_prim, st.best_mat, !st.occluded && st.found, false};
+}
+
+MCPT_DI void retry_append(const RetryList &rl, uint32_t v) {  // (one atomic per lost ray: there are next to none)
+    const uint32_t k = atomicAdd(rl.count, 1u);
+    if (k < rl.cap) rl.items[k] = v;
+}
+// end of a retrace kernel: the last workgroup to finish clears the list for the next launch
+MCPT_DI void retry_finish(const RetryList &rl) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(rl.done, 1u) == gridDim.x - 1u) {
+            *rl.count = 0u;
+            *rl.done = 0u;
+        }
+    }
 }
 
 MCPT_DI uint4 pack_hit(double t, int32_t prim, uint32_t mat_bits) {  // {t lo, t hi, prim, material | emissive << 31}
@@ -431,7 +456,7 @@ MCPT_DI uint4 pack_hit(double t, int32_t prim, uint32_t mat_bits) {  // {t lo, t
 template <int STK, bool RETRY>
 __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n_host, const uint32_t *__restrict__ n_dev,
                                                           const float4 *__restrict__ ray_o, const float4 *__restrict__ ray_d,
-                                                          uint4 *__restrict__ hit) {
+                                                          uint4 *__restrict__ hit, RetryList rl) {
     __shared__ int32_t stk[STK][kBlock];
     const int tid = threadIdx.x;
     const uint32_t n = n_dev ? *n_dev : n_host;
@@ -439,8 +464,23 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n
     for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += gridDim.x * kBlock) {
         const Ray r = make_ray(ld3(ray_o[i]), ld3(ray_d[i]));
         const TraceResult tr = traverse<false, STK, RETRY>(S, r, 0.f, stk, tid);
+        if (RETRY && tr.dropped) retry_append(rl, i);
+        else hit[i] = pack_hit(tr.t, tr.prim, tr.mat_bits);
+    }
+}
+
+// The rays k_trace_closest / k_trace_closest_refill put on their retrace list, with the scratch stack.
+__global__ __launch_bounds__(kBlock) void k_retrace_closest(DevScene S, const float4 *__restrict__ ray_o, const float4 *__restrict__ ray_d,
+                                                            uint4 *__restrict__ hit, RetryList rl) {
+    __shared__ int32_t stk[1][kBlock];
+    const uint32_t n = min(*rl.count, rl.cap);
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+        const uint32_t i = rl.items[k];
+        const Ray r = make_ray(ld3(ray_o[i]), ld3(ray_d[i]));
+        const TraceResult tr = traverse_scratch<false>(S, r, 0.f, stk, threadIdx.x);
         hit[i] = pack_hit(tr.t, tr.prim, tr.mat_bits);
     }
+    retry_finish(rl);
 }
 
 // k_trace_closest with lane refill.  Rays of one wave finish at different times (59 % lane utilisation with one ray per lane,
@@ -466,7 +506,7 @@ constexpr uint32_t kRaysPerLane = MCPT_RAYS_PER_LANE, kRefillMin = MCPT_REFILL_M
 template <int STK, bool RETRY>
 __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k_trace_closest_refill(DevScene S, uint32_t n_host, const uint32_t *__restrict__ n_dev,
                                                                  const float4 *__restrict__ ray_o, const float4 *__restrict__ ray_d,
-                                                                 uint4 *__restrict__ hit) {
+                                                                 uint4 *__restrict__ hit, RetryList rl) {
     __shared__ int32_t stk[STK][kBlock];
     const int tid = threadIdx.x;
     const uint32_t wave = (uint32_t)tid >> 6;
@@ -489,16 +529,8 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
             // ---- finished lanes: store, refill
             const bool idle = cur == kNoWork && leaf == kNoWork;
             if (idle && my >= 0) {
-                if (RETRY && dropped) {  // trace it again with the scratch stack
-                    TraceState st2;
-#ifdef MCPT_TRAVERSAL_STATS
-                    st2.nv = st2.nt = st2.iters = st2.maxsp = 0;
-#endif
-                    traverse_again<false>(S, r, 0.f, stk, tid, false, st2);
-                    hit[my] = pack_hit(st2.best_t, st2.best_prim, st2.best_mat);
-                } else {
-                    hit[my] = pack_hit(best_t, best_prim, best_mat);
-                }
+                if (RETRY && dropped) retry_append(rl, (uint32_t)my);  // (k_retrace_closest traces it again)
+                else hit[my] = pack_hit(best_t, best_prim, best_mat);
                 my = -1;
             }
             const unsigned long long im = __ballot(idle);
@@ -509,7 +541,8 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
                     r = make_ray(ld3(ray_o[idx]), ld3(ray_d[idx]));
                     if (!ray_is_plain(r)) {  // rare (a zero direction component): the NaN-faithful generic path, right away
                         const TraceResult tr = traverse<false, STK, RETRY>(S, r, 0.f, stk, tid);
-                        hit[idx] = pack_hit(tr.t, tr.prim, tr.mat_bits);
+                        if (RETRY && tr.dropped) retry_append(rl, idx);
+                        else hit[idx] = pack_hit(tr.t, tr.prim, tr.mat_bits);
                     } else {
                         my = (int32_t)idx;
                         qr = make_qray(S, r);
@@ -599,7 +632,7 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
 template <int STK, bool RETRY>
 __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Counters *__restrict__ counters, int next_idx, uint32_t cap,
                                                          const float4 *__restrict__ shq_o, const float4 *__restrict__ shq_d,
-                                                         float *__restrict__ contrib) {
+                                                         float *__restrict__ contrib, RetryList rl) {
     __shared__ int32_t stk[STK][kBlock];
     const int tid = threadIdx.x;
     const uint32_t n_found = counters->n_shadow[next_idx].v;
@@ -610,8 +643,28 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Count
         const float4 o = shq_o[e], d = shq_d[e];
         const Ray r = make_ray(ld3(o), ld3(d));
         const TraceResult tr = traverse<true, STK, RETRY>(S, r, d.w, stk, tid, found);
-        if (!tr.visible) contrib[__float_as_uint(o.w)] = 0.f;  // Scene.cpp:74-79: an invisible sample adds nothing
+        if (RETRY && tr.dropped) retry_append(rl, i);  // (undecided: k_retrace_shadow)
+        else if (!tr.visible) contrib[__float_as_uint(o.w)] = 0.f;  // Scene.cpp:74-79: an invisible sample adds nothing
     }
+}
+
+// The shadow rays k_trace_shadow put on its retrace list (queue positions), with the scratch stack.
+__global__ __launch_bounds__(kBlock) void k_retrace_shadow(DevScene S, const Counters *__restrict__ counters, int next_idx, uint32_t cap,
+                                                           const float4 *__restrict__ shq_o, const float4 *__restrict__ shq_d,
+                                                           float *__restrict__ contrib, RetryList rl) {
+    __shared__ int32_t stk[1][kBlock];
+    const uint32_t n_found = counters->n_shadow[next_idx].v;
+    const uint32_t n = min(*rl.count, rl.cap);
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+        const uint32_t i = rl.items[k];
+        const bool found = i < n_found;
+        const uint32_t e = found ? i : cap - 1u - (i - n_found);
+        const float4 o = shq_o[e], d = shq_d[e];
+        const Ray r = make_ray(ld3(o), ld3(d));
+        const TraceResult tr = traverse_scratch<true>(S, r, d.w, stk, threadIdx.x, found);
+        if (!tr.visible) contrib[__float_as_uint(o.w)] = 0.f;
+    }
+    retry_finish(rl);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -680,49 +733,42 @@ MCPT_DI void camera_ray(const CameraConst &cam, uint32_t seed, uint32_t m, uint3
     dir = mat3_mul(cam.orient, dir);  // Renderer.cpp:76
 }
 
-// k_primary: Renderer.cpp:44-79 up to the first Scene::intersect of castRay (Scene.cpp:87) for new samples.
-// The three channel paths of a sample share the primary ray, so it is generated and traced once.
+// The camera ray of sample s and its closest hit among the pixel's candidate primitives, when it has a short list (csrc/mcpt_cull.hip);
+// returns false when the ray has to walk the tree.
+MCPT_DI bool primary_ray(const DevScene &S, const CameraConst &cam, const RenderConst &C, int q, uint32_t s, f3 &pos, f3 &dir, TraceResult &tr) {
+    uint32_t pl, ks;
+    split_sample(C, q, s, pl, ks);
+    const uint32_t m = C.pixel_list ? C.pixel_list[pl] : pl;
+    const uint32_t k = (uint32_t)(q ? C.sample_offset[1] : C.sample_offset[0]) + ks;
+    camera_ray(cam, C.seed, m, k, pos, dir);
+    const int4 cd = C.pixel_cand ? C.pixel_cand[pl] : make_int4(kCandTraverse, 0, 0, 0);
+    if (cd.x == kCandTraverse) return false;
+    // every primitive a ray of this pixel can hit is in the list: test those, with the traversal's tie rule
+    const Ray r = make_ray(pos, dir);
+    const int32_t cs[4] = {cd.x, cd.y, cd.z, cd.w};
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        if (cs[q4] == kCandNone) continue;
+        const int32_t prim = ~cs[q4];
+        double t = 0;
+        if (prim_hit(S, prim, r, t) && (t < tr.t || (t == tr.t && prim > tr.prim))) {
+            tr.t = t;
+            tr.prim = prim;
+            tr.mat_bits = prim < S.n_tri ? S.tri_geom[prim].mat_bits : S.spheres[prim - S.n_tri].mat_bits;
+        }
+    }
+    return true;
+}
+
+// What follows the closest hit of a new sample (all lanes of the workgroup call it; `valid` lanes hold a sample):
 //   miss (Scene.cpp:88-95) ............ result[3 channels] = environment, no records
 //   depth-0 emitter (Scene.cpp:102-107)  result[3 channels] = clamp(0,1, emission * |wo.n|), no records
 //   surface ........................... one ray + hit entry, three fresh path records, three clamp-stack slots
-template <int STK, bool RETRY>
-__global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam, RenderConst C, Wave next, int next_idx, int q,
-                                                    uint32_t first_sample, uint32_t n_samples) {
-    __shared__ int32_t stk[STK][kBlock];
-    __shared__ BlockAllocShared sh;
-    const int tid = threadIdx.x;
-    const uint32_t j = blockIdx.x * kBlock + tid;
-    const bool valid = j < n_samples;
-    const uint32_t s = first_sample + j;
+MCPT_DI void primary_finish(const DevScene &S, const RenderConst &C, const Wave &next, int next_idx, int q, uint32_t s, bool valid, f3 pos, f3 dir,
+                            const TraceResult &tr, BlockAllocShared &sh) {
     bool surface = false;
-    f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1);
-    TraceResult tr{DBL_MAX, -1, 0u, false};
     float *const result = q ? C.result[1] : C.result[0];
     if (valid) {
-        uint32_t pl, ks;
-        split_sample(C, q, s, pl, ks);
-        const uint32_t m = C.pixel_list ? C.pixel_list[pl] : pl;
-        const uint32_t k = (uint32_t)(q ? C.sample_offset[1] : C.sample_offset[0]) + ks;
-        camera_ray(cam, C.seed, m, k, pos, dir);
-        const Ray r = make_ray(pos, dir);
-        const int4 cd = C.pixel_cand ? C.pixel_cand[pl] : make_int4(kCandTraverse, 0, 0, 0);
-        if (cd.x == kCandTraverse) {
-            tr = traverse<false, STK, RETRY>(S, r, 0.f, stk, tid);
-        } else {
-            // every primitive a ray of this pixel can hit is in the list (csrc/mcpt_cull.hip): test those, with the traversal's tie rule
-            const int32_t cs[4] = {cd.x, cd.y, cd.z, cd.w};
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                if (cs[q4] == kCandNone) continue;
-                const int32_t prim = ~cs[q4];
-                double t = 0;
-                if (prim_hit(S, prim, r, t) && (t < tr.t || (t == tr.t && prim > tr.prim))) {
-                    tr.t = t;
-                    tr.prim = prim;
-                    tr.mat_bits = prim < S.n_tri ? S.tri_geom[prim].mat_bits : S.spheres[prim - S.n_tri].mat_bits;
-                }
-            }
-        }
         if (tr.prim < 0) {
             const f3 env = sample_env(S, dir);
             result[(size_t)s * 3 + 0] = env.x;
@@ -764,6 +810,49 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
     next.ray_d[ri] = make_float4(dir.x, dir.y, dir.z, 0.f);
     next.hit[ri] = pack_hit(tr.t, tr.prim, tr.mat_bits);
     next.fresh[k] = make_uint2(s | (q ? 0x80000000u : 0u), idx[1]);
+}
+
+// k_primary: Renderer.cpp:44-79 up to the first Scene::intersect of castRay (Scene.cpp:87) for new samples.
+// The three channel paths of a sample share the primary ray, so it is generated and traced once.
+template <int STK, bool RETRY>
+__global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam, RenderConst C, Wave next, int next_idx, int q,
+                                                    uint32_t first_sample, uint32_t n_samples, RetryList rl) {
+    __shared__ int32_t stk[STK][kBlock];
+    __shared__ BlockAllocShared sh;
+    const int tid = threadIdx.x;
+    const uint32_t j = blockIdx.x * kBlock + tid;
+    bool valid = j < n_samples;
+    const uint32_t s = first_sample + j;
+    f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1);
+    TraceResult tr{DBL_MAX, -1, 0u, false, false};
+    if (valid) {
+        if (!primary_ray(S, cam, C, q, s, pos, dir, tr)) {
+            tr = traverse<false, STK, RETRY>(S, make_ray(pos, dir), 0.f, stk, tid);
+            if (RETRY && tr.dropped) {  // the sample is finished by k_primary_retrace
+                retry_append(rl, s);
+                valid = false;
+            }
+        }
+    }
+    primary_finish(S, C, next, next_idx, q, s, valid, pos, dir, tr, sh);
+}
+
+// The samples k_primary put on its retrace list: the same, with the scratch stack (a fixed grid strides over the list).
+__global__ __launch_bounds__(kBlock) void k_primary_retrace(DevScene S, CameraConst cam, RenderConst C, Wave next, int next_idx, int q, RetryList rl) {
+    __shared__ int32_t stk[1][kBlock];
+    __shared__ BlockAllocShared sh;
+    const uint32_t n = min(*rl.count, rl.cap);
+    for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {  // uniform trip count per workgroup
+        const uint32_t j = base + threadIdx.x;
+        const bool valid = j < n;
+        const uint32_t s = valid ? rl.items[j] : 0u;
+        f3 pos = mk3(0, 0, 0), dir = mk3(0, 0, 1);
+        TraceResult tr{DBL_MAX, -1, 0u, false, false};
+        if (valid && !primary_ray(S, cam, C, q, s, pos, dir, tr)) tr = traverse_scratch<false>(S, make_ray(pos, dir), 0.f, stk, threadIdx.x);
+        primary_finish(S, C, next, next_idx, q, s, valid, pos, dir, tr, sh);
+        __syncthreads();  // `sh` is reused by the next round
+    }
+    retry_finish(rl);
 }
 
 // mcpt_cast_rays: caller-supplied rays, one fresh record per ray; the rays are traced by k_trace_closest.
@@ -1411,11 +1500,13 @@ void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, uint32_t
     hipLaunchKernelGGL(k_init_free, dim3(blocks(pool)), dim3(kBlock), 0, s, free_slots, c, pool, start, mask);
 }
 
-// Stack flavour by tree height (see MCPT_STK_PUSH): <= 17 levels: 16 LDS entries; <= 20: kStkB; <= 24: 24; deeper: the retry flavour (16 LDS entries).
-// (-DMCPT_LDS_ONLY_STACKS: the former 24 / 32 / 48-entry LDS stacks for deep trees, for A/B measurements; -DMCPT_FORCE_RETRY, the
-// checking build: the retry flavour for every tree, with -DMCPT_STK_RETRY=4 LDS entries, so that most rays are traced again.)
+// Stack flavour by tree height (see MCPT_STK_PUSH): <= 17 levels: 16 LDS entries; <= 20: kStkB; <= kPlainMaxHeight (24): 24; deeper: the retry
+// flavour (16 LDS entries, retrace list).  (-DMCPT_LDS_ONLY_STACKS: 24 / 32 / 48-entry LDS stacks for deep trees instead, for A/B measurements;
+// -DMCPT_FORCE_RETRY, the checking build: the retry flavour for every tree with -DMCPT_STK_RETRY=4 LDS entries, so that most rays are
+// traced again.)  RETRACE: the launch of the retrace kernel, issued right behind a retry-flavour kernel on the same stream.
+constexpr uint32_t kRetraceGrid = 256;
 #ifdef MCPT_LDS_ONLY_STACKS
-#define MCPT_STACK_DISPATCH(height, KERNEL, ...)                                                   \
+#define MCPT_STACK_DISPATCH(height, KERNEL, RETRACE, ...)                                          \
     do {                                                                                           \
         if ((height) <= 17) hipLaunchKernelGGL((KERNEL<16, false>), __VA_ARGS__);                  \
         else if ((height) <= 20) hipLaunchKernelGGL((KERNEL<kStkB, false>), __VA_ARGS__);          \
@@ -1424,22 +1515,30 @@ void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, uint32_t
         else hipLaunchKernelGGL((KERNEL<kMaxBvhHeight, false>), __VA_ARGS__);                      \
     } while (0)
 #elif defined(MCPT_FORCE_RETRY)
-#define MCPT_STACK_DISPATCH(height, KERNEL, ...) hipLaunchKernelGGL((KERNEL<kStkRetry, true>), __VA_ARGS__)
+#define MCPT_STACK_DISPATCH(height, KERNEL, RETRACE, ...)                                          \
+    do {                                                                                           \
+        hipLaunchKernelGGL((KERNEL<kStkRetry, true>), __VA_ARGS__);                                \
+        RETRACE;                                                                                   \
+    } while (0)
 #else
-#define MCPT_STACK_DISPATCH(height, KERNEL, ...)                                                   \
+#define MCPT_STACK_DISPATCH(height, KERNEL, RETRACE, ...)                                          \
     do {                                                                                           \
         if ((height) <= 17) hipLaunchKernelGGL((KERNEL<16, false>), __VA_ARGS__);                  \
         else if ((height) <= 20) hipLaunchKernelGGL((KERNEL<kStkB, false>), __VA_ARGS__);          \
-        else if ((height) <= 24) hipLaunchKernelGGL((KERNEL<24, false>), __VA_ARGS__);             \
-        else hipLaunchKernelGGL((KERNEL<kStkRetry, true>), __VA_ARGS__);                           \
+        else if ((height) <= kPlainMaxHeight) hipLaunchKernelGGL((KERNEL<24, false>), __VA_ARGS__); \
+        else {                                                                                     \
+            hipLaunchKernelGGL((KERNEL<kStkRetry, true>), __VA_ARGS__);                            \
+            RETRACE;                                                                               \
+        }                                                                                          \
     } while (0)
 #endif
 
 void launch_primary(const DevScene &S, const CameraConst &cam, const RenderConst &C, Wave next, int next_idx, int parity,
-                    uint32_t first_sample, uint32_t n_samples, hipStream_t s) {
+                    uint32_t first_sample, uint32_t n_samples, const RetryList &rl, hipStream_t s) {
     if (n_samples == 0) return;
     const dim3 g(blocks(n_samples)), b(kBlock);
-    MCPT_STACK_DISPATCH(S.height, k_primary, g, b, 0, s, S, cam, C, next, next_idx, parity, first_sample, n_samples);
+    MCPT_STACK_DISPATCH(S.height, k_primary, hipLaunchKernelGGL(k_primary_retrace, dim3(kRetraceGrid), b, 0, s, S, cam, C, next, next_idx, parity, rl), g, b, 0, s, S,
+                        cam, C, next, next_idx, parity, first_sample, n_samples, rl);
 }
 
 void launch_generate_explicit(const RenderConst &C, Wave next, int next_idx, uint32_t n, hipStream_t s) {
@@ -1454,17 +1553,19 @@ void launch_camera_rays(const CameraConst &cam, uint32_t seed, uint32_t n, const
 }
 
 void launch_trace_closest(const DevScene &S, uint32_t n, const uint32_t *n_dev, const float4 *ray_o, const float4 *ray_d, uint4 *hit,
-                          hipStream_t s) {
+                          const RetryList &rl, hipStream_t s) {
     if (n == 0) return;
 #ifndef MCPT_NO_REFILL
     if (S.qnodes && !S.inst) {  // the common configuration: lanes refill from the wave's chunk of rays
         const dim3 g((n + kBlock * kRaysPerLane - 1) / (kBlock * kRaysPerLane)), b(kBlock);
-        MCPT_STACK_DISPATCH(S.height, k_trace_closest_refill, g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
+        MCPT_STACK_DISPATCH(S.height, k_trace_closest_refill, hipLaunchKernelGGL(k_retrace_closest, dim3(kRetraceGrid), b, 0, s, S, ray_o, ray_d, hit, rl), g, b, 0, s, S,
+                            n, n_dev, ray_o, ray_d, hit, rl);
         return;
     }
 #endif
     const dim3 g(blocks(n)), b(kBlock);
-    MCPT_STACK_DISPATCH(S.height, k_trace_closest, g, b, 0, s, S, n, n_dev, ray_o, ray_d, hit);
+    MCPT_STACK_DISPATCH(S.height, k_trace_closest, hipLaunchKernelGGL(k_retrace_closest, dim3(kRetraceGrid), b, 0, s, S, ray_o, ray_d, hit, rl), g, b, 0, s, S, n, n_dev,
+                        ray_o, ray_d, hit, rl);
 }
 
 void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_grid, hipStream_t s) {
@@ -1473,13 +1574,15 @@ void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X
 }
 
 void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, uint32_t cap, Scratch X,
-                         float *contrib, uint32_t per_cu, hipStream_t s) {
+                         float *contrib, uint32_t per_cu, const RetryList &rl, hipStream_t s) {
     if (n_max == 0) return;
     // The queue length is only known on the device.  The grid covers the upper bound (capped at 1024 workgroups per
     // CU, far more than are resident, so the hardware balances uneven rays dynamically: a persistent 8-per-CU grid
     // was 30 % slower on the Cornell box); workgroups past the end of the queue exit at once, longer queues stride.
     const dim3 g(std::min<uint32_t>(blocks(n_max), 256u * per_cu)), b(kBlock);
-    MCPT_STACK_DISPATCH(S.height, k_trace_shadow, g, b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib);
+    MCPT_STACK_DISPATCH(S.height, k_trace_shadow,
+                        hipLaunchKernelGGL(k_retrace_shadow, dim3(kRetraceGrid), b, 0, s, S, counters, next_idx, cap, X.shq_o, X.shq_d, contrib, rl), g, b, 0, s, S,
+                        counters, next_idx, cap, X.shq_o, X.shq_d, contrib, rl);
 }
 
 void launch_shade(const DevScene &S, const RenderConst &C, Wave cur, Wave next, Scratch X, int cur_idx, uint32_t n_cur_max,

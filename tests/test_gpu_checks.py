@@ -69,10 +69,11 @@ def test_skipped_direct_lighting_is_exactly_zero(pkg, hip, hip_check, oracle, na
 
 @pytest.mark.parametrize("builder", ["sah", "lbvh", "reference"])
 def test_retry_flavour_of_the_traversal_stack(pkg, hip, hip_check, builder):
-    """Trees deeper than 20 levels are traversed with 16 stack entries in LDS; a ray that would need more loses an entry, is marked,
-    and is traced again with a per-lane stack in scratch memory (stk_push / traverse_again in csrc/mcpt_kernels.hip) -- which no ray
-    of these scenes needs.  The checking build uses that flavour for every tree with FOUR LDS entries, so most of its rays are
-    traced twice: same intersections, same frames, same counters."""
+    """Trees deeper than 24 levels are traversed with 16 stack entries in LDS; a ray that would need more loses an entry, is marked and
+    put on the kernel's retrace list, and a small kernel launched right behind traces the listed rays again with a per-lane stack in
+    scratch memory (MCPT_STK_PUSH / RetryList / k_retrace_* in csrc/mcpt_kernels.hip) -- which no ray of these scenes needs.  The
+    checking build uses that flavour for every tree with FOUR LDS entries, so most of its rays (primary, continuation and shadow) go
+    through the lists: same intersections, same frames, same counters."""
     rng = np.random.default_rng(11)
     for sd in (pkg.scenes.chess_scene(width=160, height=90, spp=4), pkg.scenes.chess_high(160, 90, 4), pkg.scenes.cornell_demo(64, 64, 4)):
         prod, chk = hip.HipScene(sd, builder=builder), hip.HipScene(sd, library=hip_check, builder=builder)
