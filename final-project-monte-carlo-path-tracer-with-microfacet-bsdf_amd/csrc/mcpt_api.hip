@@ -304,8 +304,9 @@ hipError_t ensure_workspace(PoolCtx &ctx, uint32_t pool, int32_t n_dir, int32_t 
     if ((e = w.vtx1.alloc(pool)) != hipSuccess) return e;
     if ((e = w.vtx2.alloc(pool)) != hipSuccess) return e;
     if ((e = w.vtx_j.alloc(pool)) != hipSuccess) return e;
-    if ((e = w.shq_o.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
-    if ((e = w.shq_d.alloc((size_t)pool * n_dir)) != hipSuccess) return e;
+    const size_t shq = (size_t)kShadowShards * shadow_region((uint32_t)std::min<uint64_t>((uint64_t)pool * n_dir, 0xffffffffull));  // (sharded: Counters)
+    if ((e = w.shq_o.alloc(shq)) != hipSuccess) return e;
+    if ((e = w.shq_d.alloc(shq)) != hipSuccess) return e;
     if ((e = w.stack.alloc((size_t)pool * max_depth)) != hipSuccess) return e;
     uint64_t ring = 1;
     // free-slot ring: a power of two, so that the 32-bit head/tail counters may wrap, and at least twice the pool: the entries
@@ -424,6 +425,8 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     // continuation rays / direct-lighting vertices per record, as observed in the last iteration: they size the grids of the
     // kernels that are queued before the host knows the true lengths (grid-stride kernels: any grid is correct)
     double cont_ratio = 1.0, direct_ratio = 1.0;
+    double shadow_ratio = 1.0;      // shadow rays per light sample, as observed (sizes the grid of k_trace_shadow; any grid is correct)
+    uint32_t n_direct_prev = 0;     // length of the k_direct work list of the previous iteration
     bool n_cur_exact = false;  // n_cur_max is the true list length (false right after the prologue: an upper bound)
     long it = 0;
     std::vector<long> issue_done_iter(P, -1);
@@ -598,7 +601,12 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             T.end(ev, K_DIRECT, st);
             if (C.enable_shadow) {
                 ev = T.begin(st);
-                launch_trace_shadow(sc->view, w.counters.p, nxt, grid_direct * (uint32_t)n_dir, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, K.shadow_grid_per_cu, w.retry.list(1), st);
+                // (every workgroup of k_trace_shadow pays for the prefix sums of the queue's shards before it knows whether it has work:
+                // the grid follows the observed number of shadow rays per light sample instead of covering every light sample)
+                const uint32_t n_samples_max = grid_direct * (uint32_t)n_dir;
+                const uint32_t grid_shadow = std::max<uint32_t>(std::min<uint32_t>(n_samples_max, 1024u * 256u),
+                                                                std::min<uint32_t>(n_samples_max, (uint32_t)(1.5 * shadow_ratio * n_samples_max) + 4096u));
+                launch_trace_shadow(sc->view, w.counters.p, nxt, grid_shadow, (uint32_t)C.pool * (uint32_t)n_dir, w.scratch(), nx.contrib, K.shadow_grid_per_cu, w.retry.list(1), st);
                 T.end(ev, K_SHADOW, st);
             }
         }
@@ -619,7 +627,13 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
                 cont_ratio = (double)n_cont / n_cur_max;
                 direct_ratio = (double)n_direct / n_cur_max;
             }
+            if (n_direct_prev > 0) {  // the queue k_direct filled in the previous iteration (list `cur`, not yet cleared by k_bookkeep when read back)
+                uint64_t n_sh = 0;
+                for (uint32_t k = 0; k < kShadowShards; ++k) n_sh += w.h_counters->n_shadow[cur][k].v + w.h_counters->n_shadow_w[cur][k].v;
+                shadow_ratio = std::min(1.0, (double)n_sh / ((double)n_direct_prev * n_dir));
+            }
         }
+        n_direct_prev = n_direct;
         n_cur_max = n_next;
         n_cur_exact = true;
         cur = nxt;
@@ -635,7 +649,8 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     tot.shaded += hc.tot_shaded + hc.tot_ended + hc.ended.v;
     tot.direct += hc.tot_direct;
     tot.closest += hc.tot_cont;
-    tot.shadow += hc.tot_shadow + hc.n_shadow[0].v + hc.n_shadow[1].v + hc.n_shadow_w[0].v + hc.n_shadow_w[1].v;
+    tot.shadow += hc.tot_shadow;
+    for (uint32_t k = 0; k < kShadowShards; ++k) tot.shadow += hc.n_shadow[0][k].v + hc.n_shadow[1][k].v + hc.n_shadow_w[0][k].v + hc.n_shadow_w[1][k].v;
     return MCPT_OK;
 }
 

@@ -19,10 +19,19 @@ struct alignas(128) HotCounter {
     uint32_t v;
     uint32_t pad[31];
 };
+// The shadow-ray queue is written by k_direct without workgroup barriers: every WAVE reserves its entries with one atomic per kind, on the
+// counter of its shard (wave index modulo kShadowShards), so that no single counter sees more than 1/32 of the atomics.  Shard s owns the
+// region [s R, (s + 1) R) of the queue arrays, R = shadow_region(capacity): entries whose light sample was already found in the window
+// fill it from the front, the others from the back; k_trace_shadow turns a queue position into an entry with the prefix sums of the 32
+// counts.  (A compact queue with one counter per workgroup needed two barriers per round of k_direct: 40 % of the kernel.)
+constexpr uint32_t kShadowShards = 32;
+__host__ __device__ inline uint32_t shadow_region(uint32_t capacity) {  // entries per shard: whole waves, enough for every wave that maps to it
+    return (((capacity + 63u) / 64u + kShadowShards - 1u) / kShadowShards) * 64u;
+}
 struct Counters {
     HotCounter n_paths[2];  // records in path list 0 / 1
     HotCounter n_rays[2];   // entries in closest-hit queue 0 / 1
-    HotCounter n_shadow[2]; // entries in the shadow-ray queue (indexed like the list the rays belong to)
+    HotCounter n_shadow[2][kShadowShards];  // per shard: shadow rays whose light sample was found (indexed like the list the rays belong to)
     HotCounter n_direct[2]; // vertices that need direct lighting: length of the k_direct work list (same indexing)
     // Free clamp-stack slots: a ring of a power-of-two number of entries.  k_primary pops at `free_head`, k_shade pushes at
     // `free_tail` (both only ever increase; entry = counter & mask), so the two kernels can run concurrently: the host only
@@ -33,7 +42,7 @@ struct Counters {
     HotCounter pushes;      // recursion levels entered (castRay depth+1 calls); folded into tot_pushes by k_bookkeep
     HotCounter overflow;    // cumulative: paths cut by max_depth
     HotCounter ended;       // vertices shaded and finished in the same k_shade call (no record); folded into tot_ended
-    HotCounter n_shadow_w[2]; // shadow rays that still need the window search; stored from the END of the queue arrays
+    HotCounter n_shadow_w[2][kShadowShards];  // per shard: shadow rays that still need the window search; stored from the END of the shard's region
     // cumulative totals kept on the device by k_bookkeep (the host does not see every iteration's counts)
     unsigned long long tot_shaded, tot_direct, tot_shadow, tot_cont, tot_iterations, tot_pushes, tot_ended;
 };

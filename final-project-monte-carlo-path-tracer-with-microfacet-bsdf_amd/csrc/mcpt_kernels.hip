@@ -626,6 +626,44 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
     }
 }
 
+// Queue position -> entry of the sharded shadow queue (Counters): positions [0, pf[K]) are the entries whose light sample was found, shard
+// by shard; the next pw[K] positions the others.  pf / pw: exclusive prefix sums of the shards' counts (K + 1 values each, in LDS).
+MCPT_DI void shadow_prefix(const Counters *counters, int next_idx, uint32_t *pf, uint32_t *pw) {  // all threads of the workgroup call it
+    if (threadIdx.x < 64) {
+        const uint32_t t = threadIdx.x;
+        uint32_t cf = t < kShadowShards ? counters->n_shadow[next_idx][t].v : 0u;
+        uint32_t cw = t < kShadowShards ? counters->n_shadow_w[next_idx][t].v : 0u;
+        uint32_t sf = cf, sw = cw;
+        for (int o = 1; o < 64; o <<= 1) {  // inclusive scan over the wave
+            const uint32_t a = (uint32_t)__shfl_up((int)sf, o), b = (uint32_t)__shfl_up((int)sw, o);
+            if ((int)t >= o) {
+                sf += a;
+                sw += b;
+            }
+        }
+        if (t < kShadowShards) {
+            pf[t] = sf - cf;
+            pw[t] = sw - cw;
+        }
+        if (t == kShadowShards - 1u) {
+            pf[kShadowShards] = sf;
+            pw[kShadowShards] = sw;
+        }
+    }
+    __syncthreads();
+}
+MCPT_DI uint32_t shadow_entry(const uint32_t *pf, const uint32_t *pw, uint32_t i, uint32_t region, bool &found) {
+    const uint32_t nf = pf[kShadowShards];
+    found = i < nf;
+    const uint32_t *p = found ? pf : pw;
+    const uint32_t j = found ? i : i - nf;
+    uint32_t s = 0;  // the largest shard index with p[s] <= j (an empty shard shares its prefix with the next one: the later one wins)
+    for (uint32_t step = kShadowShards / 2; step; step >>= 1)
+        if (p[s + step] <= j) s += step;
+    const uint32_t off = j - p[s];
+    return found ? s * region + off : (s + 1u) * region - 1u - off;
+}
+
 // Shadow queue consumer: a fixed grid strides over the queue, whose length is only known on the device.
 // Items [0, n_found) are the front of the arrays (light sample already found: occluder search only), the next n_window
 // items are read from the back (window search first), so that the long occluder searches fill whole waves.
@@ -634,12 +672,14 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Count
                                                          const float4 *__restrict__ shq_o, const float4 *__restrict__ shq_d,
                                                          float *__restrict__ contrib, RetryList rl) {
     __shared__ int32_t stk[STK][kBlock];
+    __shared__ uint32_t pf[kShadowShards + 1], pw[kShadowShards + 1];
     const int tid = threadIdx.x;
-    const uint32_t n_found = counters->n_shadow[next_idx].v;
-    const uint32_t n = n_found + counters->n_shadow_w[next_idx].v;
+    shadow_prefix(counters, next_idx, pf, pw);
+    const uint32_t n = pf[kShadowShards] + pw[kShadowShards];
+    const uint32_t region = shadow_region(cap);
     for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += gridDim.x * kBlock) {
-        const bool found = i < n_found;
-        const uint32_t e = found ? i : cap - 1u - (i - n_found);
+        bool found;
+        const uint32_t e = shadow_entry(pf, pw, i, region, found);
         const float4 o = shq_o[e], d = shq_d[e];
         const Ray r = make_ray(ld3(o), ld3(d));
         const TraceResult tr = traverse<true, STK, RETRY>(S, r, d.w, stk, tid, found);
@@ -653,12 +693,14 @@ __global__ __launch_bounds__(kBlock) void k_retrace_shadow(DevScene S, const Cou
                                                            const float4 *__restrict__ shq_o, const float4 *__restrict__ shq_d,
                                                            float *__restrict__ contrib, RetryList rl) {
     __shared__ int32_t stk[1][kBlock];
-    const uint32_t n_found = counters->n_shadow[next_idx].v;
+    __shared__ uint32_t pf[kShadowShards + 1], pw[kShadowShards + 1];
+    shadow_prefix(counters, next_idx, pf, pw);
+    const uint32_t region = shadow_region(cap);
     const uint32_t n = min(*rl.count, rl.cap);
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
         const uint32_t i = rl.items[k];
-        const bool found = i < n_found;
-        const uint32_t e = found ? i : cap - 1u - (i - n_found);
+        bool found;
+        const uint32_t e = shadow_entry(pf, pw, i, region, found);
         const float4 o = shq_o[e], d = shq_d[e];
         const Ray r = make_ray(ld3(o), ld3(d));
         const TraceResult tr = traverse_scratch<true>(S, r, d.w, stk, threadIdx.x, found);
@@ -888,8 +930,10 @@ __global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Coun
         c->free_tail.v = start + pool;
         c->n_prays[0].v = c->n_prays[1].v = 0;
         c->live[0].v = c->live[1].v = 0;
-        c->n_shadow[0].v = c->n_shadow[1].v = 0;
-        c->n_shadow_w[0].v = c->n_shadow_w[1].v = 0;
+        for (uint32_t k = 0; k < kShadowShards; ++k) {
+            c->n_shadow[0][k].v = c->n_shadow[1][k].v = 0;
+            c->n_shadow_w[0][k].v = c->n_shadow_w[1][k].v = 0;
+        }
         c->n_direct[0].v = c->n_direct[1].v = 0;
         c->pushes.v = 0;
         c->overflow.v = 0;
@@ -1246,8 +1290,12 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
 // adds nothing to l_dir whether it is visible or not, so it casts no shadow ray; a NaN contribution is not zero
 // and is traced.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock, 8) void k_direct(DevScene S, RenderConst C, Wave next, Scratch Xs, int next_idx) {
-    __shared__ BlockAllocShared sh;
+// (7 waves per SIMD: 70 VGPRs, nothing spilled.  With the former workgroup-wide queue allocation 8 had been better -- more waves to
+// hide its barriers; with the per-wave allocation below, 8 spills 27 registers: frame 4880 against 5000.)
+#ifndef MCPT_DIRECT_WAVES
+#define MCPT_DIRECT_WAVES 7
+#endif
+__global__ __launch_bounds__(kBlock, MCPT_DIRECT_WAVES) void k_direct(DevScene S, RenderConst C, Wave next, Scratch Xs, int next_idx) {
     const uint32_t n_dir = (uint32_t)C.n_dir;
     const uint32_t total = C.counters->n_direct[next_idx].v * n_dir;  // the grid is sized from an estimate: stride over the list
     for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {  // uniform trip count per block
@@ -1316,18 +1364,26 @@ __global__ __launch_bounds__(kBlock, 8) void k_direct(DevScene S, RenderConst C,
         }
 #endif
     }
-    const bool want[2] = {cast && !window, cast && window};
-    const uint32_t mult[2] = {1u, 1u};
-    uint32_t *const ctr[2] = {&C.counters->n_shadow[next_idx].v, &C.counters->n_shadow_w[next_idx].v};
-    const bool sub[2] = {false, false};
-    uint32_t idx[2];
-    block_alloc<2>(sh, want, mult, ctr, sub, idx);
-    if (cast) {
-        const uint32_t e = window ? (uint32_t)C.pool * (uint32_t)C.n_dir - 1u - idx[1] : idx[0];
-        Xs.shq_o[e] = make_float4(q.x, q.y, q.z, __uint_as_float(target));
-        Xs.shq_d[e] = make_float4(ws.x, ws.y, ws.z, dist);
+    // queue entries: one atomic per wave and kind on the counters of the wave's shard (see Counters): no barrier, no LDS
+    const unsigned long long mf = __ballot(cast && !window), mw = __ballot(cast && window);
+    if (mf | mw) {
+        const uint32_t shard = (g >> 6) & (kShadowShards - 1u);
+        uint32_t bf = 0, bw = 0;
+        if (lane_id() == 0) {
+            if (mf) bf = atomicAdd(&C.counters->n_shadow[next_idx][shard].v, (uint32_t)__popcll(mf));
+            if (mw) bw = atomicAdd(&C.counters->n_shadow_w[next_idx][shard].v, (uint32_t)__popcll(mw));
+        }
+        bf = (uint32_t)__shfl((int)bf, 0);
+        bw = (uint32_t)__shfl((int)bw, 0);
+        if (cast) {
+            const uint32_t region = shadow_region((uint32_t)C.pool * n_dir);
+            const unsigned long long m = window ? mw : mf;
+            const uint32_t off = (window ? bw : bf) + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const uint32_t e = window ? (shard + 1u) * region - 1u - off : shard * region + off;
+            Xs.shq_o[e] = make_float4(q.x, q.y, q.z, __uint_as_float(target));
+            Xs.shq_d[e] = make_float4(ws.x, ws.y, ws.z, dist);
+        }
     }
-    __syncthreads();  // `sh` is reused by the next round
     }
 }
 
@@ -1462,9 +1518,12 @@ __global__ void k_bookkeep(Counters *c, int cur_idx, int from_host, uint32_t n_n
     const int nxt = cur_idx ^ 1;
     switch (threadIdx.x) {  // one lane per field: the global accesses are independent and overlap
     case 0: {
-        const uint32_t v = c->n_shadow[cur_idx].v + c->n_shadow_w[cur_idx].v;
-        c->n_shadow[cur_idx].v = 0;
-        c->n_shadow_w[cur_idx].v = 0;
+        uint32_t v = 0;
+        for (uint32_t k = 0; k < kShadowShards; ++k) {
+            v += c->n_shadow[cur_idx][k].v + c->n_shadow_w[cur_idx][k].v;
+            c->n_shadow[cur_idx][k].v = 0;
+            c->n_shadow_w[cur_idx][k].v = 0;
+        }
         c->tot_shadow += v;
         break;
     }
