@@ -426,7 +426,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
     // kernels that are queued before the host knows the true lengths (grid-stride kernels: any grid is correct)
     double cont_ratio = 1.0, direct_ratio = 1.0;
     double shadow_ratio = 1.0;      // shadow rays per light sample, as observed (sizes the grid of k_trace_shadow; any grid is correct)
-    uint32_t n_direct_prev = 0;     // length of the k_direct work list of the previous iteration
+    uint32_t n_direct_prev = 0, n_direct_prev2 = 0;  // lengths of the k_direct work lists of the two previous iterations
     bool n_cur_exact = false;  // n_cur_max is the true list length (false right after the prologue: an upper bound)
     long it = 0;
     std::vector<long> issue_done_iter(P, -1);
@@ -531,7 +531,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
                 T.end(ev, K_CLOSEST, st);
                 cur = nxt;
             }
-            HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, kCountersHeadBytes, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             T.collect();
             have_counters = true;
@@ -562,7 +562,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
             HIP_TRY(hipEventRecord(ctx.join[1], s_prim));
             HIP_TRY(hipStreamWaitEvent(st, ctx.join[1], 0));
         }
-        HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(w.h_counters, w.counters.p, kCountersHeadBytes, hipMemcpyDeviceToHost, st));  // (not the sharded counters)
         HIP_TRY(hipEventRecord(ctx.readback, st));
 
         // queue_ahead: the rest of the iteration is queued BEFORE the host looks at the counters.  Every kernel reads the
@@ -627,12 +627,10 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
                 cont_ratio = (double)n_cont / n_cur_max;
                 direct_ratio = (double)n_direct / n_cur_max;
             }
-            if (n_direct_prev > 0) {  // the queue k_direct filled in the previous iteration (list `cur`, not yet cleared by k_bookkeep when read back)
-                uint64_t n_sh = 0;
-                for (uint32_t k = 0; k < kShadowShards; ++k) n_sh += w.h_counters->n_shadow[cur][k].v + w.h_counters->n_shadow_w[cur][k].v;
-                shadow_ratio = std::min(1.0, (double)n_sh / ((double)n_direct_prev * n_dir));
-            }
+            // (last_shadow: the queue k_bookkeep cleared before this read-back, i.e. the one k_direct filled two iterations ago)
+            if (n_direct_prev2 > 0) shadow_ratio = std::min(1.0, (double)w.h_counters->last_shadow / ((double)n_direct_prev2 * n_dir));
         }
+        n_direct_prev2 = n_direct_prev;
         n_direct_prev = n_direct;
         n_cur_max = n_next;
         n_cur_exact = true;

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "mcpt_device.h"
 
 namespace mcpt {
@@ -31,7 +33,6 @@ __host__ __device__ inline uint32_t shadow_region(uint32_t capacity) {  // entri
 struct Counters {
     HotCounter n_paths[2];  // records in path list 0 / 1
     HotCounter n_rays[2];   // entries in closest-hit queue 0 / 1
-    HotCounter n_shadow[2][kShadowShards];  // per shard: shadow rays whose light sample was found (indexed like the list the rays belong to)
     HotCounter n_direct[2]; // vertices that need direct lighting: length of the k_direct work list (same indexing)
     // Free clamp-stack slots: a ring of a power-of-two number of entries.  k_primary pops at `free_head`, k_shade pushes at
     // `free_tail` (both only ever increase; entry = counter & mask), so the two kernels can run concurrently: the host only
@@ -42,10 +43,14 @@ struct Counters {
     HotCounter pushes;      // recursion levels entered (castRay depth+1 calls); folded into tot_pushes by k_bookkeep
     HotCounter overflow;    // cumulative: paths cut by max_depth
     HotCounter ended;       // vertices shaded and finished in the same k_shade call (no record); folded into tot_ended
-    HotCounter n_shadow_w[2][kShadowShards];  // per shard: shadow rays that still need the window search; stored from the END of the shard's region
     // cumulative totals kept on the device by k_bookkeep (the host does not see every iteration's counts)
     unsigned long long tot_shaded, tot_direct, tot_shadow, tot_cont, tot_iterations, tot_pushes, tot_ended;
+    uint32_t last_shadow;  // length of the shadow queue k_bookkeep cleared last (the host sizes the next k_trace_shadow grid from it)
+    // ---- everything above is what the host reads back every iteration (kCountersHeadBytes); the sharded counters stay on the device
+    HotCounter n_shadow[2][kShadowShards];    // per shard: shadow rays whose light sample was found (indexed like the list the rays belong to)
+    HotCounter n_shadow_w[2][kShadowShards];  // per shard: shadow rays that still need the window search; stored from the END of the shard's region
 };
+constexpr size_t kCountersHeadBytes = offsetof(Counters, n_shadow);
 
 // One side of the double-buffered wavefront state (all SoA, 16-byte records, indexed by list position).
 struct Wave {

@@ -938,6 +938,7 @@ __global__ __launch_bounds__(kBlock) void k_init_free(uint32_t *free_slots, Coun
         c->pushes.v = 0;
         c->overflow.v = 0;
         c->ended.v = 0;
+        c->last_shadow = 0;
         c->tot_shaded = c->tot_direct = c->tot_shadow = c->tot_cont = c->tot_iterations = c->tot_pushes = c->tot_ended = 0;
     }
 }
@@ -1525,6 +1526,7 @@ __global__ void k_bookkeep(Counters *c, int cur_idx, int from_host, uint32_t n_n
             c->n_shadow_w[cur_idx][k].v = 0;
         }
         c->tot_shadow += v;
+        c->last_shadow = v;
         break;
     }
     case 1: c->tot_shaded += from_host ? n_next : c->n_paths[nxt].v; break;  // (new samples have no records)
