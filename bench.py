@@ -16,6 +16,12 @@ is resident in HBM before the timed region.  With N ranks the frame is partition
 32x32 pixel tiles (strong scaling: the frame is fixed), every rank renders its tiles, and the timed
 region ends with one RCCL reduce of the framebuffer to rank 0 (torch.distributed, backend nccl).
 
+Launch: `python bench.py --gpus N` is enough.  With N > 1 and no WORLD_SIZE in the environment this process -- before it
+imports torch or touches the GPU -- starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same
+arguments>` as a CHILD process (never an exec), relays its output and exits with its code; started under torch.distributed.run
+directly (WORLD_SIZE set) it is a rank.  Every rank reports the device it runs on (index, gcnArchName, PCI bus id, uuid); the
+JSON line carries them under "ranks", and fewer distinct devices than ranks is an error unless --share-device (rehearsal).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -98,8 +104,38 @@ def load_traffic():
         return None
 
 
+def launch_ranks(args):
+    """`bench.py --gpus N` outside a launcher: run the N ranks under torch.distributed.run in a child process.  Called before torch
+    is imported: this process never initialises HIP (a GPU-initialised process must not exec or fork into another GPU program)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)  # stdout / stderr are inherited: rank 0's JSON line is this process's output
+
+
+def device_identity(torch, index):
+    """What tells two devices apart: arch name, PCI domain:bus:device, uuid (attributes probed: they vary with the torch version)."""
+    pr = torch.cuda.get_device_properties(index)
+    pci = None
+    if hasattr(pr, "pci_bus_id"):
+        pci = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, getattr(pr, "pci_device_id", 0))
+    return {"device_index": index, "name": pr.name, "gcnArchName": getattr(pr, "gcnArchName", None), "pci_bus_id": pci,
+            "uuid": str(getattr(pr, "uuid", "")) or None}
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
     import mcpt_loader
     pkg = mcpt_loader.load()
@@ -114,6 +150,9 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if args.share_device:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: local rank %d but only %d GPU(s) visible (--share-device rehearses N ranks on one GPU)"
+                         % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -122,6 +161,15 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
         else:
             dist.init_process_group(backend="gloo")
+    # which device every rank really runs on: gathered on all ranks so that all of them stop together when devices are shared
+    me = dict(device_identity(torch, local_rank), rank=rank, local_rank=local_rank, pid=os.getpid())
+    ranks_seen = [me]
+    if distributed:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
+        distinct = len({(r["pci_bus_id"], r["uuid"], r["device_index"]) for r in ranks_seen})
+        if distinct < world and not args.share_device:
+            raise SystemExit("bench.py: %d ranks but only %d distinct device(s): %s" % (world, distinct, ranks_seen))
 
     def reduce_to_rank0(t):
         if args.backend == "nccl":
@@ -216,8 +264,15 @@ def main():
             "k_primary": (agg["ms_generate"], agg["n_generate"], agg["closest_rays"] - n_cont),
             "k_direct": (agg["ms_direct"], agg["n_direct"], agg["direct_vertices"]),
             "k_shade": (agg["ms_shade"], agg["n_shade"], agg["shaded"])}
+    # Profile-derived fields (limiter, PMC traffic, serialised figures, the dominant kernel of the SERIALISED step) come from
+    # profiles/traffic.json and describe one build rendering one configuration: they are used only when this run is that
+    # configuration on that build (source tag of csrc/); otherwise the dominant kernel is the live one and those fields are null.
     prof = load_traffic() or {}
-    ser = prof.get("_serialized", {})
+    pc = prof.get("_config", {})
+    build_tag = pkg.build.source_tag()
+    prof_ok = bool(prof) and prof.get("_build_tag") == build_tag and \
+        (pc.get("scene"), pc.get("width"), pc.get("height"), pc.get("n_dir")) == (args.scene, W, H, args.n_dir)
+    ser = prof.get("_serialized", {}) if prof_ok else {}
     live_dom = max(kern, key=lambda k: kern[k][0])
     dom = max(ser, key=lambda k: ser[k].get("ms_per_step", 0.0)) if ser and not args.serialized else live_dom
     if dom not in kern:
@@ -231,21 +286,24 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         # PMC bytes per launch were measured on the serialised profile's launches; scale them to this run's launch size (bytes per
         # ray / vertex are what carries over)
-        traffic = prof.get(dom)
+        traffic = prof.get(dom) if prof_ok else None
         ser_units = ser.get(dom, {}).get("units_per_launch")
         if traffic and ser_units:
             traffic = int(traffic * (units / n_launch) / ser_units)
+        vb = ser.get(dom, {}).get("valu_busy_frac")
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": int(n_launch), "units_per_launch": round(units / n_launch, 1),
                     "algorithmic_bytes_per_unit": per_unit,
+                    "live_dom": live_dom,  # the kernel with the largest summed HIP-event time in THIS run (streams overlap)
                     "timing": "HIP events on the launch streams, timed region, %s" % ("one stream (serialised)" if args.serialized else "three overlapping streams"),
                     "traffic_GBps": None if not traffic else round(traffic / (avg_ms * 1e-3) / 1e9, 1),
                     # what actually limits this kernel (PMC pass of the serialised run): the share of its duration the SIMDs
                     # spend issuing vector instructions -- an L2-resident scene is VALU-issue bound long before HBM-bound
-                    "limiter": "valu_issue" if ser.get(dom, {}).get("valu_busy_frac", 0) > 0.6 else "hbm/latency",
-                    "valu_busy_frac": ser.get(dom, {}).get("valu_busy_frac"),
+                    "limiter": None if vb is None else ("valu_issue" if vb > 0.6 else "hbm/latency"),
+                    "valu_busy_frac": vb,
                     "serialized": ser.get(dom),
+                    "profile": {"applies": prof_ok, "build_tag": build_tag, "profile_build_tag": prof.get("_build_tag"), "profile_config": pc or None},
                     "kernel_ms": {k: round(v[0], 2) for k, v in kern.items()},
                     "kernel_launches": {k: int(v[1]) for k, v in kern.items()},
                     "kernel_units": {k: int(v[2]) for k, v in kern.items()}}
@@ -253,7 +311,7 @@ def main():
     ref_gbs = value * 1e6 * ref_bytes_per_sample / 1e9
     traced_bytes_per_sample = (BYTES_PER_RAY * (tot_closest + tot_shadow) + BYTES_PER_VERTEX * tot_vertices) / tot_samples + BYTES_PER_SAMPLE
     jt = prof.get("_job", {})
-    hbm_bps = jt.get("hbm_bytes_per_sample") if (args.scene == "chess" and args.n_dir == 4 and (W, H) == (1920, 1080)) else None
+    hbm_bps = jt.get("hbm_bytes_per_sample") if prof_ok else None
 
     # ---- parity vs the CPU oracle, same Philox seed, on a reduced configuration of the same scene
     parity = None
@@ -291,7 +349,7 @@ def main():
 
     out = {
         "metric": "Msamples/s (pixels x spp), chess scene 1920x1080, PSNR vs CPU",
-        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "ranks": ranks_seen, "backend": args.backend if distributed else None, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %dx%d, %d spp per step, n_dir_sample %d, RR %.2f, DoF %s, constant sky colour"

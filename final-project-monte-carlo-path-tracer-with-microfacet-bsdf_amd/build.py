@@ -29,6 +29,17 @@ def hipcc():
     return "hipcc"
 
 
+def source_tag():
+    """Identifies the kernel sources a library was built from: sha1 over csrc/ sources, headers and the compiler flags (12 hex digits).
+    profiles/traffic.json records it, and bench.py applies that profile only to the build it was measured on."""
+    import hashlib
+    h = hashlib.sha1(" ".join(FLAGS).encode())
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
 def needs_build(lib=LIB):
     if not os.path.exists(lib):
         return True

@@ -54,3 +54,23 @@ def test_two_rank_tile_partition_and_reduce(tmp_path, pkg, oracle):
     fb1, _ = oracle.OracleScene(sd).render(spp=2, seed=5)
     assert np.array_equal(fb1, fb2)  # disjoint tiles + identical Philox keys: bit-identical to the 1-rank frame
     assert 0 < owned <= 64 * 48  # every lit pixel was produced by exactly one rank
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent must start two ranks under torch.distributed.run (as a
+    child process, before importing torch) instead of running one rank and printing n_gpus 1.  Without a GPU every rank stops at the
+    "needs a GPU" check (the product has no CPU fallback), so the run fails -- with both ranks' messages and no JSON line."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check (the GPU version is tests/test_gpu_multi.py)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert p.returncode != 0
+    assert "starting 2 ranks" in p.stderr and "--nproc-per-node 2" in p.stderr
+    assert p.stderr.count("bench.py needs a GPU") >= 2
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    # one rank needs no launcher and says the same
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert p1.returncode != 0 and "starting" not in p1.stderr and "bench.py needs a GPU" in p1.stderr

@@ -3,11 +3,10 @@
 Inside the boundary: mcpt_group_* with every entry naming device 0 rehearses the schedule the library runs on N GPUs -- one
 replica and one host thread per entry, interleaved-tile partition, merge into the first frame -- and must reproduce the
 one-GPU frame bit for bit (with distinct devices the merge is one RCCL ncclReduce; that leg needs an N-GPU node).
-Outside: bench.py's one-process-per-GPU path (torch.distributed) is run with 2 ranks sharing the GPU over gloo, in fresh child
-processes exactly as the driver launches it, and must write the PNG the 1-rank run writes."""
+Outside: bench.py's one-process-per-GPU path (torch.distributed) is run as plain `python bench.py --gpus 2` (bench.py starts its
+ranks itself) with both ranks sharing the GPU over gloo, and must write the PNG the 1-rank run writes."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
@@ -76,30 +75,37 @@ def test_cpp_executable_on_two_replicas(pkg, hip, tmp_path):
     assert outs[0] == outs[1]
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 def test_bench_two_ranks_write_the_one_rank_png(tmp_path):
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), both ranks on cuda:0, reduce
-    through gloo; the PNG of the reduced frame is byte-identical to the 1-rank run's."""
+    """Plain `python bench.py --gpus 2` -- no launcher: bench.py starts its two ranks itself (a child torch.distributed.run, before the
+    parent touches the GPU) -- both ranks on cuda:0, reduce through gloo; the JSON line says n_gpus 2 and names both ranks' device, and the
+    PNG of the reduced frame is byte-identical to the 1-rank run's."""
     common = ["--steps", "2", "--warmup", "1", "--spp-per-step", "3", "--width", "320", "--height", "180", "--no-cpu-baseline", "--no-psnr"]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     one = str(tmp_path / "one.png")
     p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--save-png", one] + common,
                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert p1.returncode == 0, p1.stderr[-2000:]
     two = str(tmp_path / "two.png")
-    p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo",
-                         "--save-png", two] + common, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--save-png", two] + common,
+                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert p2.returncode == 0, p2.stderr[-2000:]
     j1 = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][-1])
     j2 = json.loads([l for l in p2.stdout.splitlines() if l.startswith("{")][-1])
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["value"] > 0
+    assert [r["rank"] for r in j2["ranks"]] == [0, 1] and len({r["pid"] for r in j2["ranks"]}) == 2
+    assert all(r["gcnArchName"] and r["gcnArchName"].startswith("gfx950") for r in j2["ranks"])
     assert j2["job"]["vertices_per_sample"] == j1["job"]["vertices_per_sample"]  # the same work, split over two ranks
     assert open(one, "rb").read() == open(two, "rb").read()
+
+
+def test_bench_refuses_ranks_without_their_own_device(tmp_path):
+    """Two ranks on a one-GPU box without --share-device: every rank must stop with a message, and bench.py with a non-zero code,
+    instead of quietly rendering on one GPU and printing n_gpus 1."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a one-GPU box")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--spp-per-step", "1",
+                        "--width", "64", "--height", "64", "--no-cpu-baseline", "--no-psnr"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert p.returncode != 0
+    assert "GPU(s) visible" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]

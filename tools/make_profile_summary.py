@@ -17,6 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "profiles"))
+sys.path.insert(0, ROOT)
 from summarize_pmc import short  # noqa: E402
 
 SIMDS, CLOCK_HZ, CYCLES_PER_VALU = 1024, 2.4e9, 4
@@ -59,6 +60,10 @@ def main(d, tag):
     out["_serialized"] = ser
     out["_job"] = {"hbm_bytes_per_sample": round(total_bytes / samples, 1), "samples_in_step": samples,
                    "source": "profiles/%s_pmc_summary_no_overlap_64spp_step.json" % tag}
+    cfg = bench.get("config", {}).get("workload", "")
+    import mcpt_loader
+    out["_build_tag"] = mcpt_loader.load().build.source_tag()  # bench.py applies this profile only to the build it was measured on ...
+    out["_config"] = {"scene": "chess", "width": 1920, "height": 1080, "n_dir": 4, "workload": cfg}  # ... rendering this configuration (tools/profile_round.sh)
     out["_bench_serialized"] = {"value": bench["value"], "kernel_ms": bench["roofline"]["kernel_ms"], "kernel_launches": bench["roofline"].get("kernel_launches")}
     out["_note"] = ("Serialised run (`bench.py --serialized --steps 1 --warmup 0 --spp-per-step 64`, build %s, tools/profile_round.sh): "
                     "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches from separate rocprofv3 --pmc passes; FETCH_SIZE doubled "
