@@ -1033,6 +1033,28 @@ int orc_intersect(const orc_scene *s, int64_t n, const float *origins, const flo
     return 0;
 }
 
+/* What the camera rays of a frame see: for pixel m and sample k < spp (Renderer.cpp:36-76, depth of field included) the primitive
+ * Scene::intersect returns for the primary ray, out_prim[m * spp + k] (-1: background).  Used by the tests that pin the scene
+ * assembly, camera and depth of field against the images the reference ships. */
+int orc_primary_hits(const orc_scene *s, const orc_camera *cam, uint32_t seed, int32_t spp, int32_t *out_prim) {
+    if (!s || !cam || !out_prim || spp <= 0) return 1;
+    const int W = cam->width, H = cam->height;
+    float scale = (float)tan((double)deg2rad(cam->fov * 0.5f));
+    float aspect = cam->width / (float)cam->height;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int m = 0; m < H * W; ++m) {
+        counters c = {0, 0, 0, 0};
+        for (int k = 0; k < spp; ++k) {
+            v3 pos, dir;
+            camera_ray(cam, scale, aspect, seed, (uint32_t)m, (uint32_t)k, &pos, &dir);
+            ray r = make_ray(pos, dir);
+            intersection it = scene_intersect(s, &r, &c);
+            out_prim[(size_t)m * (size_t)spp + (size_t)k] = it.happened ? it.obj->prim_id : -1;
+        }
+    }
+    return 0;
+}
+
 int orc_cast_rays(const orc_scene *s, const orc_params *p, int64_t n, const float *origins, const float *dirs,
                   const uint32_t *pixel, const uint32_t *sample, const int32_t *channel, float *out) {
     if (!s || !p) return 1;

@@ -103,6 +103,9 @@ int orc_render(const orc_scene *s, const orc_camera *cam, const orc_params *p, f
 int orc_intersect(const orc_scene *s, int64_t n, const float *origins, const float *dirs, double *out_t,
                   int32_t *out_prim);
 
+/* Primary visibility of a frame: out_prim[m * spp + k] = primitive the camera ray of pixel m, sample k hits (-1: none). */
+int orc_primary_hits(const orc_scene *s, const orc_camera *cam, uint32_t seed, int32_t spp, int32_t *out_prim);
+
 /* Scene::castRay(ray, 0, channel) (Scene.cpp:85-184) on a ray list; RNG keyed by (seed, pixel[i], sample[i], channel[i]). */
 int orc_cast_rays(const orc_scene *s, const orc_params *p, int64_t n, const float *origins, const float *dirs,
                   const uint32_t *pixel, const uint32_t *sample, const int32_t *channel, float *out);

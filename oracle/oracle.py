@@ -57,6 +57,8 @@ def lib():
         L.orc_intersect.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_cast_rays.restype = C.c_int
         L.orc_cast_rays.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int64] + [C.c_void_p] * 6
+        L.orc_primary_hits.restype = C.c_int
+        L.orc_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p]
         L.orc_camera_ray.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_material_eval.restype = C.c_float
         L.orc_material_eval.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_int]
@@ -155,6 +157,16 @@ class OracleScene:
         prim = np.zeros(n, dtype=np.int32)
         lib().orc_intersect(self.h, n, _ptr(o), _ptr(d), _ptr(t), _ptr(prim))
         return t, prim
+
+    def primary_hits(self, spp, seed=1, camera=None):
+        """[H, W, spp] int32: the primitive every camera ray of the frame hits (-1: background), depth of field included."""
+        cam = np.ascontiguousarray(camera if camera is not None else self.sd.camera)
+        W, H = int(cam["width"].reshape(-1)[0]), int(cam["height"].reshape(-1)[0])
+        out = np.zeros((H, W, int(spp)), dtype=np.int32)
+        rc = lib().orc_primary_hits(self.h, _ptr(cam), int(seed), int(spp), _ptr(out))
+        if rc != 0:
+            raise RuntimeError("orc_primary_hits failed: %d" % rc)
+        return out
 
     def cast_rays(self, origins, dirs, pixel, sample, channel, **kw):
         o, d = _f3(origins), _f3(dirs)
