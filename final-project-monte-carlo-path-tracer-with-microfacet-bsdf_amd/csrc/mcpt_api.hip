@@ -159,6 +159,7 @@ struct Knobs {
     uint32_t ring_start = 0;    // MCPT_RING_START: the free ring's counters start here (exercises the 2^32 wrap)
     int host_delay_us = 0;      // MCPT_HOST_DELAY_US: a slow host
     bool sky_cull = true;       // MCPT_SKY_CULL=0: trace the pixels that can only see the background too
+    bool small_scene = true;    // MCPT_SMALL_SCENE=0: no LDS-resident flavour for scenes of a few KB
     uint64_t fake_free_mb = 0;  // MCPT_FAKE_FREE_MB: pretend that only this much device memory is free (exercises the pool shrink)
     void read() {
         auto off = [](const char *n) { const char *v = std::getenv(n); return v && v[0] == '0'; };
@@ -166,6 +167,7 @@ struct Knobs {
         queue_ahead = !off("MCPT_QUEUE_AHEAD");
         timing = !off("MCPT_TIMING");
         sky_cull = !off("MCPT_SKY_CULL");
+        small_scene = !off("MCPT_SMALL_SCENE");
         const char *v;
         if ((v = std::getenv("MCPT_POOLS"))) pools = (v[0] == '2') ? 2 : 1;
         if ((v = std::getenv("MCPT_DRAIN_BATCH"))) drain_batch = std::max(1, std::atoi(v));
@@ -1040,6 +1042,19 @@ int mcpt_scene_create_ex(const mcpt_scene_desc *desc, int device, const mcpt_bui
     v.height = hs.height;
     for (int k = 0; k < 3; ++k) v.light_center[k] = hs.light_center[k];
     v.light_radius = hs.light_radius;
+    v.n_inner = sc->n_inner;
+    v.n_sphere_slots = (int32_t)hs.spheres.size();
+    v.n_mats = (int32_t)hs.materials.size();
+    v.n_light_nodes = (int32_t)hs.light_nodes.size();
+    v.n_light_tris = (int32_t)hs.light_tris.size();
+    // the LDS-resident flavour (SMALL kernels): everything the traversal and light sampling read fits the kSmall* limits
+    v.small = 0;
+#if !defined(MCPT_FORCE_RETRY) && !defined(MCPT_LDS_ONLY_STACKS)
+    if (sc->knobs.small_scene && !v.inst && v.root >= 0 && v.n_inner <= kSmallNodes && v.n_tri <= kSmallTris && v.n_sphere_slots <= kSmallSphereSlots &&
+        v.n_mats <= kSmallMats && v.n_lights <= kSmallLights && v.n_light_nodes <= kSmallLightNodes && v.n_light_tris <= kSmallLightTris &&
+        v.height - 1 <= kSmallStk)
+        v.small = 1;
+#endif
     v.dbg = nullptr;
 #if defined(MCPT_TRAVERSAL_STATS) || defined(MCPT_CHECK_DIRECT_SKIP)
     if (sc->dbg.alloc(16) == hipSuccess) {
@@ -1052,6 +1067,7 @@ int mcpt_scene_create_ex(const mcpt_scene_desc *desc, int device, const mcpt_bui
     sc->info.builder = hs.builder;
     sc->info.quantised = sc->qnodes.p ? 1 : 0;
     sc->info.n_instances = (int32_t)hs.instances.size();
+    sc->info.lds_resident = v.small;
     sc->info.n_nodes = sc->n_inner;
     sc->info.bvh_height = hs.height;
     sc->info.n_lights = v.n_lights;

@@ -101,6 +101,9 @@ struct DevScene {
     float background[3];
     float light_center[3], light_radius, light_area_sum;
     int32_t root, n_tri, n_lights, env_w, env_h, height;
+    // Small-scene flavour (kernels' SMALL template flag, mcpt_kernels.hip): the whole traversal data set -- nodes, TriGeom, spheres -- and
+    // the light tables fit a few KB, and every workgroup copies them into LDS once.  The counts say how much there is to copy.
+    int32_t small, n_inner, n_sphere_slots, n_mats, n_light_nodes, n_light_tris;
     unsigned long long *dbg;  // traversal statistics (only written by -DMCPT_TRAVERSAL_STATS builds)
 };
 

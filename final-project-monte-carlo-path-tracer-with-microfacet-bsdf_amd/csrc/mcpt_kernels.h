@@ -112,6 +112,13 @@ struct CameraConst {
     float orient[9];
 };
 
+// Small-scene flavour (DevScene::small): what the SMALL kernels can hold in LDS -- nodes (64-B or 32-B records), TriGeom, sphere records
+// (one slot per object), materials and light tables -- and the depth of their traversal stack.  The Cornell configurations are 31-34
+// nodes, 32 triangles, 9 objects, 7-8 materials, one two-triangle light.
+constexpr int kSmallNodes = 64, kSmallTris = 64, kSmallSphereSlots = 16;
+constexpr int kSmallMats = 12, kSmallLights = 4, kSmallLightNodes = 8, kSmallLightTris = 8;
+constexpr int kSmallStk = 8;  // LDS stack entries of the SMALL kernels: trees of up to 9 levels
+
 // Retrace list of one traversal kernel (retry flavour of the traversal stack, MCPT_STK_PUSH in mcpt_kernels.hip): the rays of a launch that
 // lost a stack entry; the retrace kernel launched right behind traces them again with the scratch stack and clears the list.  `cap` is the
 // largest number of rays one launch can hold, so the list cannot overflow.

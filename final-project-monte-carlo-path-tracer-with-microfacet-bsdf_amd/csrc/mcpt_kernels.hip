@@ -103,6 +103,56 @@ MCPT_DI f3 ld3(float4 v) { return mk3(v.x, v.y, v.z); }
 // XCD turns the frame's spatial cost variation into XCD load imbalance.  The scene fits every L2 anyway.)
 
 // ------------------------------------------------------------------------------------------------
+// Small scenes (the Cornell configurations: 31-34 nodes, 32 triangles, 3 spheres, 7 KB in all): the SMALL instantiations of the
+// traversal kernels copy nodes, TriGeom and sphere records into LDS once per workgroup and repoint their by-value DevScene at the
+// copy, so every node visit and primitive test reads LDS instead of the vector cache; the traversal stack is 8 entries (trees of up
+// to 9 levels).  A wave-uniform template flavour: there is no LDS / global select inside the loop (that select is what sank
+// the top-of-tree staging experiment on the chess scene).  The pointers are generic ones derived from __shared__
+// arrays; after inlining the compiler's address-space inference turns the loads into ds_read_b128 (tools/kernel_resources.py shows
+// no flat_load in the SMALL kernels' loops).
+// ------------------------------------------------------------------------------------------------
+// (limits: kSmall* in mcpt_kernels.h; mcpt_scene_create decides `DevScene::small` from them)
+struct alignas(16) SmallGeomLds {
+    uint4 nodes[kSmallNodes * 4];  // Node records (64 B), or QNode records (32 B) in the first half
+    TriGeom tri[kSmallTris];
+    SphereRec sph[kSmallSphereSlots];
+};
+struct alignas(16) SmallLightLds {
+    MaterialRec mats[kSmallMats];
+    LightRec lights[kSmallLights];
+    LightNode nodes[kSmallLightNodes];
+    LightTri tris[kSmallLightTris];
+};
+MCPT_DI void lds_copy16(void *dst, const void *src, uint32_t n16) {  // n16 16-byte words, by the whole workgroup
+    uint4 *d = reinterpret_cast<uint4 *>(dst);
+    const uint4 *g = reinterpret_cast<const uint4 *>(src);
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) d[i] = g[i];
+}
+// (the caller's __syncthreads follows: a kernel that stages both blocks pays for one barrier)
+MCPT_DI void stage_small_geom(DevScene &S, SmallGeomLds &L) {
+    // (both node pointers end up as LDS pointers or null on every path, so that the address-space inference sees no global / LDS mix)
+    const bool quant = S.qnodes != nullptr;
+    if (quant) lds_copy16(L.nodes, S.qnodes, (uint32_t)S.n_inner * (uint32_t)(sizeof(QNode) / 16));
+    else lds_copy16(L.nodes, S.nodes, (uint32_t)S.n_inner * (uint32_t)(sizeof(Node) / 16));
+    S.nodes = reinterpret_cast<const Node *>(L.nodes);
+    S.qnodes = quant ? reinterpret_cast<const QNode *>(L.nodes) : nullptr;
+    lds_copy16(L.tri, S.tri_geom, (uint32_t)S.n_tri * (uint32_t)(sizeof(TriGeom) / 16));
+    lds_copy16(L.sph, S.spheres, (uint32_t)S.n_sphere_slots * (uint32_t)(sizeof(SphereRec) / 16));
+    S.tri_geom = L.tri;
+    S.spheres = L.sph;
+}
+MCPT_DI void stage_small_lights(DevScene &S, SmallLightLds &L) {
+    lds_copy16(L.mats, S.mats, (uint32_t)S.n_mats * (uint32_t)(sizeof(MaterialRec) / 16));
+    lds_copy16(L.lights, S.lights, (uint32_t)S.n_lights * (uint32_t)(sizeof(LightRec) / 16));
+    lds_copy16(L.nodes, S.light_nodes, (uint32_t)S.n_light_nodes * (uint32_t)(sizeof(LightNode) / 16));
+    lds_copy16(L.tris, S.light_tris, (uint32_t)S.n_light_tris * (uint32_t)(sizeof(LightTri) / 16));
+    S.mats = L.mats;
+    S.lights = L.lights;
+    S.light_nodes = L.nodes;
+    S.light_tris = L.tris;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Traversal.  One lane per ray; the per-lane stack of child references lives in LDS as
 // stk[level][thread] so that the 64 lanes of a wave hit 64 consecutive banks.
 //
@@ -453,11 +503,16 @@ MCPT_DI uint4 pack_hit(double t, int32_t prim, uint32_t mat_bits) {  // {t lo, t
     return make_uint4((uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)prim, mat_bits);
 }
 
-template <int STK, bool RETRY>
+template <int STK, bool RETRY, bool SMALL>
 __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n_host, const uint32_t *__restrict__ n_dev,
                                                           const float4 *__restrict__ ray_o, const float4 *__restrict__ ray_d,
                                                           uint4 *__restrict__ hit, RetryList rl) {
     __shared__ int32_t stk[STK][kBlock];
+    if constexpr (SMALL) {
+        __shared__ SmallGeomLds small_geom;
+        stage_small_geom(S, small_geom);
+        __syncthreads();
+    }
     const int tid = threadIdx.x;
     const uint32_t n = n_dev ? *n_dev : n_host;
     // grid-stride: when the length is only known on the device the host sizes the grid from an estimate
@@ -487,8 +542,10 @@ __global__ __launch_bounds__(kBlock) void k_retrace_closest(DevScene S, const fl
 // profiles/r02_traversal_stats.txt).  Here a wave owns a chunk of kRaysPerLane x 64 consecutive rays and, at the top of every round
 // of the speculative loop, lanes whose ray has finished store its hit and -- once at least kRefillMin lanes are idle -- take the next
 // rays of the chunk (ballot + prefix count: no atomics, no persistent grid: the grid is still one workgroup per 1024 rays).
-// The common configuration only (quantised nodes, no instancing); a ray with a zero direction component is traced on the spot by
-// the generic path.  Same tests per ray as traverse_loop<kClosest, STK, true, true, false>, hence the same hits.
+// The common configuration only (quantised nodes, no instancing); the rays of the chunk that have a zero direction component are traced
+// by the generic path before the loop starts (round 3: tracing them inside a refill, with the rest of the wave parked in the middle of
+// its own walks, lost the rest of the chunk when a refill handed out nothing but such rays -- tests/test_gpu_small_scene.py has the
+// case).  Same tests per ray as traverse_loop<kClosest, STK, true, true, false>, hence the same hits.
 #ifndef MCPT_REFILL_MIN
 #define MCPT_REFILL_MIN 16
 #endif
@@ -503,11 +560,16 @@ constexpr uint32_t kRaysPerLane = MCPT_RAYS_PER_LANE, kRefillMin = MCPT_REFILL_M
 #ifndef MCPT_REFILL_WAVES
 #define MCPT_REFILL_WAVES 7
 #endif
-template <int STK, bool RETRY>
+template <int STK, bool RETRY, bool SMALL>
 __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k_trace_closest_refill(DevScene S, uint32_t n_host, const uint32_t *__restrict__ n_dev,
                                                                  const float4 *__restrict__ ray_o, const float4 *__restrict__ ray_d,
                                                                  uint4 *__restrict__ hit, RetryList rl) {
     __shared__ int32_t stk[STK][kBlock];
+    if constexpr (SMALL) {
+        __shared__ SmallGeomLds small_geom;
+        stage_small_geom(S, small_geom);
+        __syncthreads();
+    }
     const int tid = threadIdx.x;
     const uint32_t wave = (uint32_t)tid >> 6;
     const uint32_t n = n_dev ? *n_dev : n_host;
@@ -525,6 +587,25 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
         int32_t cur = kNoWork, leaf = kNoWork;
         int sp = 0;
         bool dropped = false;  // RETRY: this ray lost a stack entry (see MCPT_STK_PUSH)
+        // Rays with a zero direction component (non-finite reciprocals: rare) need the NaN-faithful slab chain, which the loop below
+        // does not carry.  They are traced first, by the generic path, with the whole wave at one place (a wave without such a ray
+        // pays for four direction loads per lane, which the refills below then find in the cache); the refill skips them.
+        for (uint32_t k = 0; k < kRaysPerLane; ++k) {
+            const uint32_t idx = next + k * 64u + lane_id();
+            bool odd = false;
+            Ray ro = r;
+            if (idx < end) {
+                ro = make_ray(ld3(ray_o[idx]), ld3(ray_d[idx]));
+                odd = !ray_is_plain(ro);
+            }
+            if (__any(odd)) {
+                if (odd) {
+                    const TraceResult tr = traverse<false, STK, RETRY>(S, ro, 0.f, stk, tid);
+                    if (RETRY && tr.dropped) retry_append(rl, idx);
+                    else hit[idx] = pack_hit(tr.t, tr.prim, tr.mat_bits);
+                }
+            }
+        }
         while (true) {
             // ---- finished lanes: store, refill
             const bool idle = cur == kNoWork && leaf == kNoWork;
@@ -539,11 +620,7 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
                 const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
                 if (idle && idx < end) {
                     r = make_ray(ld3(ray_o[idx]), ld3(ray_d[idx]));
-                    if (!ray_is_plain(r)) {  // rare (a zero direction component): the NaN-faithful generic path, right away
-                        const TraceResult tr = traverse<false, STK, RETRY>(S, r, 0.f, stk, tid);
-                        if (RETRY && tr.dropped) retry_append(rl, idx);
-                        else hit[idx] = pack_hit(tr.t, tr.prim, tr.mat_bits);
-                    } else {
+                    if (ray_is_plain(r)) {  // (the others were traced before the loop: the lane stays idle and is refilled again)
                         my = (int32_t)idx;
                         qr = make_qray(S, r);
                         lim = INFINITY;
@@ -561,7 +638,10 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
                 }
                 next += n_idle;
             }
-            if (!__any(my >= 0)) break;
+            if (!__any(my >= 0)) {
+                if (next < end) continue;  // every ray just handed out had been traced before the loop: hand out the next ones
+                break;
+            }
             // ---- phase 1: inner nodes (see traverse_loop)
             while (true) {
                 if (cur >= 0) {
@@ -667,13 +747,17 @@ MCPT_DI uint32_t shadow_entry(const uint32_t *pf, const uint32_t *pw, uint32_t i
 // Shadow queue consumer: a fixed grid strides over the queue, whose length is only known on the device.
 // Items [0, n_found) are the front of the arrays (light sample already found: occluder search only), the next n_window
 // items are read from the back (window search first), so that the long occluder searches fill whole waves.
-template <int STK, bool RETRY>
+template <int STK, bool RETRY, bool SMALL>
 __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Counters *__restrict__ counters, int next_idx, uint32_t cap,
                                                          const float4 *__restrict__ shq_o, const float4 *__restrict__ shq_d,
                                                          float *__restrict__ contrib, RetryList rl) {
     __shared__ int32_t stk[STK][kBlock];
     __shared__ uint32_t pf[kShadowShards + 1], pw[kShadowShards + 1];
     const int tid = threadIdx.x;
+    if constexpr (SMALL) {  // (made visible by the barrier at the end of shadow_prefix)
+        __shared__ SmallGeomLds small_geom;
+        stage_small_geom(S, small_geom);
+    }
     shadow_prefix(counters, next_idx, pf, pw);
     const uint32_t n = pf[kShadowShards] + pw[kShadowShards];
     const uint32_t region = shadow_region(cap);
@@ -856,11 +940,16 @@ MCPT_DI void primary_finish(const DevScene &S, const RenderConst &C, const Wave 
 
 // k_primary: Renderer.cpp:44-79 up to the first Scene::intersect of castRay (Scene.cpp:87) for new samples.
 // The three channel paths of a sample share the primary ray, so it is generated and traced once.
-template <int STK, bool RETRY>
+template <int STK, bool RETRY, bool SMALL>
 __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam, RenderConst C, Wave next, int next_idx, int q,
                                                     uint32_t first_sample, uint32_t n_samples, RetryList rl) {
     __shared__ int32_t stk[STK][kBlock];
     __shared__ BlockAllocShared sh;
+    if constexpr (SMALL) {
+        __shared__ SmallGeomLds small_geom;
+        stage_small_geom(S, small_geom);
+        __syncthreads();
+    }
     const int tid = threadIdx.x;
     const uint32_t j = blockIdx.x * kBlock + tid;
     bool valid = j < n_samples;
@@ -1296,7 +1385,20 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
 #ifndef MCPT_DIRECT_WAVES
 #define MCPT_DIRECT_WAVES 7
 #endif
+// SMALL: light tables, materials and the triangles / spheres in LDS (small scenes, see SmallGeomLds).
+// (Round 3, measured and not kept: for these scenes, where 75-86 % of the light samples do cast a ray, the shadow query run right here in
+// the lane that made the sample -- no queue entry, no prefix sums, no second launch.  Correct, and slower: cornell_rc 784^2 spp 256
+// 427 against 475 Msamples/s, DEMO 1080p 755 against 857: the fused kernel took 288 ms where k_direct + k_trace_shadow take 112 + 137
+// side by side with the other chains.)
+template <bool SMALL>
 __global__ __launch_bounds__(kBlock, MCPT_DIRECT_WAVES) void k_direct(DevScene S, RenderConst C, Wave next, Scratch Xs, int next_idx) {
+    if constexpr (SMALL) {
+        __shared__ SmallGeomLds small_geom;
+        __shared__ SmallLightLds small_lights;
+        stage_small_geom(S, small_geom);
+        stage_small_lights(S, small_lights);
+        __syncthreads();
+    }
     const uint32_t n_dir = (uint32_t)C.n_dir;
     const uint32_t total = C.counters->n_direct[next_idx].v * n_dir;  // the grid is sized from an estimate: stride over the list
     for (uint32_t base = blockIdx.x * kBlock; base < total; base += gridDim.x * kBlock) {  // uniform trip count per block
@@ -1357,13 +1459,13 @@ __global__ __launch_bounds__(kBlock, MCPT_DIRECT_WAVES) void k_direct(DevScene S
                 }
             }
         }
-        next.contrib[target] = c;
 #ifdef MCPT_CHECK_DIRECT_SKIP
         if (((bits >> 19) & 1u) && S.dbg) {
             atomicAdd(&S.dbg[14], 1ull);
             if (!(c == 0.f)) atomicAdd(&S.dbg[15], 1ull);
         }
 #endif
+        next.contrib[target] = c;
     }
     // queue entries: one atomic per wave and kind on the counters of the wave's shard (see Counters): no barrier, no LDS
     const unsigned long long mf = __ballot(cast && !window), mw = __ballot(cast && window);
@@ -1569,26 +1671,27 @@ constexpr uint32_t kRetraceGrid = 256;
 #ifdef MCPT_LDS_ONLY_STACKS
 #define MCPT_STACK_DISPATCH(height, KERNEL, RETRACE, ...)                                          \
     do {                                                                                           \
-        if ((height) <= 17) hipLaunchKernelGGL((KERNEL<16, false>), __VA_ARGS__);                  \
-        else if ((height) <= 20) hipLaunchKernelGGL((KERNEL<kStkB, false>), __VA_ARGS__);          \
-        else if ((height) <= 24) hipLaunchKernelGGL((KERNEL<24, false>), __VA_ARGS__);             \
-        else if ((height) <= 32) hipLaunchKernelGGL((KERNEL<32, false>), __VA_ARGS__);             \
-        else hipLaunchKernelGGL((KERNEL<kMaxBvhHeight, false>), __VA_ARGS__);                      \
+        if ((height) <= 17) hipLaunchKernelGGL((KERNEL<16, false, false>), __VA_ARGS__);           \
+        else if ((height) <= 20) hipLaunchKernelGGL((KERNEL<kStkB, false, false>), __VA_ARGS__);   \
+        else if ((height) <= 24) hipLaunchKernelGGL((KERNEL<24, false, false>), __VA_ARGS__);      \
+        else if ((height) <= 32) hipLaunchKernelGGL((KERNEL<32, false, false>), __VA_ARGS__);      \
+        else hipLaunchKernelGGL((KERNEL<kMaxBvhHeight, false, false>), __VA_ARGS__);               \
     } while (0)
 #elif defined(MCPT_FORCE_RETRY)
 #define MCPT_STACK_DISPATCH(height, KERNEL, RETRACE, ...)                                          \
     do {                                                                                           \
-        hipLaunchKernelGGL((KERNEL<kStkRetry, true>), __VA_ARGS__);                                \
+        hipLaunchKernelGGL((KERNEL<kStkRetry, true, false>), __VA_ARGS__);                         \
         RETRACE;                                                                                   \
     } while (0)
 #else
 #define MCPT_STACK_DISPATCH(height, KERNEL, RETRACE, ...)                                          \
     do {                                                                                           \
-        if ((height) <= 17) hipLaunchKernelGGL((KERNEL<16, false>), __VA_ARGS__);                  \
-        else if ((height) <= 20) hipLaunchKernelGGL((KERNEL<kStkB, false>), __VA_ARGS__);          \
-        else if ((height) <= kPlainMaxHeight) hipLaunchKernelGGL((KERNEL<24, false>), __VA_ARGS__); \
+        if (S.small) hipLaunchKernelGGL((KERNEL<kSmallStk, false, true>), __VA_ARGS__); /* scene in LDS */ \
+        else if ((height) <= 17) hipLaunchKernelGGL((KERNEL<16, false, false>), __VA_ARGS__);      \
+        else if ((height) <= 20) hipLaunchKernelGGL((KERNEL<kStkB, false, false>), __VA_ARGS__);   \
+        else if ((height) <= kPlainMaxHeight) hipLaunchKernelGGL((KERNEL<24, false, false>), __VA_ARGS__); \
         else {                                                                                     \
-            hipLaunchKernelGGL((KERNEL<kStkRetry, true>), __VA_ARGS__);                            \
+            hipLaunchKernelGGL((KERNEL<kStkRetry, true, false>), __VA_ARGS__);                     \
             RETRACE;                                                                               \
         }                                                                                          \
     } while (0)
@@ -1631,7 +1734,9 @@ void launch_trace_closest(const DevScene &S, uint32_t n, const uint32_t *n_dev, 
 
 void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_grid, hipStream_t s) {
     if (n_vertices_grid == 0) return;
-    hipLaunchKernelGGL(k_direct, dim3(blocks(n_vertices_grid * (uint32_t)C.n_dir)), dim3(kBlock), 0, s, S, C, next, X, next_idx);
+    const dim3 g(blocks(n_vertices_grid * (uint32_t)C.n_dir)), b(kBlock);
+    if (S.small) hipLaunchKernelGGL((k_direct<true>), g, b, 0, s, S, C, next, X, next_idx);
+    else hipLaunchKernelGGL((k_direct<false>), g, b, 0, s, S, C, next, X, next_idx);
 }
 
 void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, uint32_t cap, Scratch X,

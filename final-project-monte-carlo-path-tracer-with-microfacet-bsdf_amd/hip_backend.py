@@ -63,7 +63,7 @@ BUILDERS = {"default": 0, "sah": 1, "reference": 2, "lbvh": 3}  # MCPT_BUILD_*
 class SceneInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("bvh_height", C.c_int32), ("n_lights", C.c_int32), ("n_prims", C.c_int32),
                 ("scene_bytes", C.c_uint64), ("build_ms", C.c_double), ("upload_ms", C.c_double), ("builder", C.c_int32),
-                ("quantised", C.c_int32), ("n_instances", C.c_int32), ("pad", C.c_int32)]
+                ("quantised", C.c_int32), ("n_instances", C.c_int32), ("lds_resident", C.c_int32)]
 
 
 _libs = {}

@@ -205,7 +205,7 @@ typedef struct {
     int32_t builder;  /* 0 host binned SAH, 1 host reference topology (median split), 2 GPU LBVH */
     int32_t quantised;/* 1: 32-byte nodes with 16-bit boxes are traversed */
     int32_t n_instances; /* objects whose traversal nodes are shared with a prototype (0: plain tree) */
-    int32_t pad;
+    int32_t lds_resident; /* 1: the scene is small enough for the kernels that copy nodes, triangles, spheres and light tables into LDS */
 } mcpt_scene_info;
 int mcpt_scene_get_info(const mcpt_scene *scene, mcpt_scene_info *info);
 
