@@ -163,6 +163,18 @@ inline int traversal_stack_entries(int height) {
     return height <= 17 ? 16 : (height <= 20 ? kStkB : (height <= kPlainMaxHeight ? 24 : (height <= kMaxBvhHeight ? kMaxBvhHeight : 0)));  // (deeper: 16 in LDS, and the scratch stack of kMaxBvhHeight entries for the rays that need more)
 }
 
+// The two halves of mcpt_scene_create (csrc/mcpt_api.hip), exposed for mcpt_group_create (csrc/mcpt_multi.hip), which flattens the scene
+// and builds its tree once and then uploads it to every device from one thread per device.
+struct HostBuild {
+    HostScene hs;
+    BuildChoice choice;
+    double build_ms = 0.0;  // flattening + host tree build
+    double init_ms = 0.0;   // first use of the device by this process (context, code objects), overlapped with the host build
+};
+int build_scene_host(const mcpt_scene_desc *desc, const mcpt_build_options *options, HostBuild &hb);
+int upload_scene(const mcpt_scene_desc *desc, HostBuild &hb, int device, mcpt_scene **out);
+double warm_up_device(int device);
+
 void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, uint32_t start, uint32_t mask, hipStream_t s);
 // After k_shade(cur -> next): adds this iteration's list lengths to the cumulative totals and clears the counters of
 // list `cur` (consumed; it is the next iteration's output list), in one launch.

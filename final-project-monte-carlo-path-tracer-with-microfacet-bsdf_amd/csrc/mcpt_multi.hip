@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -70,6 +71,7 @@ struct mcpt_group {
     bool same_device = true;
     RcclApi rccl;
     std::vector<ncclComm_t> comms;
+    double build_ms = 0.0, setup_ms = 0.0;  // host build (once); all of mcpt_group_create
 };
 
 namespace {
@@ -112,10 +114,13 @@ int mcpt_group_create(const mcpt_scene_desc *desc, int n_devices, const int *dev
     g->streams.assign(n_devices, nullptr);
     g->same_device = true;
     for (int i = 1; i < n_devices; ++i) g->same_device = g->same_device && devices[i] == devices[0];
-    // Diagnostic: MCPT_GROUP_FORCE_RCCL=1 sends a ONE-device group through the RCCL merge as well (a communicator of one rank), so
-    // that the library loading, communicator set-up and the ncclReduce call can be exercised on a one-GPU box.
+#ifdef MCPT_TEST_HOOKS
+    // Test hook of the checking build only (libmcpt_hip_check.so): MCPT_GROUP_FORCE_RCCL=1 sends a ONE-device group through the RCCL merge
+    // as well (a communicator of one rank), so that the library loading, communicator set-up and the ncclReduce call can be exercised on
+    // a one-GPU box.
     const char *force = std::getenv("MCPT_GROUP_FORCE_RCCL");
     if (n_devices == 1 && force && force[0] == '1') g->same_device = false;
+#endif
     if (!g->same_device)
         for (int i = 0; i < n_devices; ++i)
             for (int j = 0; j < i; ++j)
@@ -123,23 +128,91 @@ int mcpt_group_create(const mcpt_scene_desc *desc, int n_devices, const int *dev
                     mcpt_group_destroy(g);
                     return gfail(MCPT_ERR_ARG, "mcpt_group_create: a device may appear once (or every entry names the same device: rehearsal)");
                 }
-    for (int i = 0; i < n_devices; ++i) {
-        const int rc = mcpt_scene_create(desc, devices[i], &g->scenes[i]);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        mcpt_group_destroy(g);
+        return gfail(MCPT_ERR_HIP, "mcpt_group_create: no HIP device available (this library has no CPU fallback)");
+    }
+    for (int i = 0; i < n_devices; ++i)
+        if (devices[i] < 0 || devices[i] >= ndev) {
+            mcpt_group_destroy(g);
+            return gfail(MCPT_ERR_ARG, "mcpt_group_create: device " + std::to_string(devices[i]) + ": device index out of range");
+        }
+    // The scene is flattened and its tree built ONCE, on the calling thread, while one helper thread per distinct device brings that
+    // device up (context, code objects); then one thread per entry copies the flattened scene to its device.  (Round 2 rebuilt the tree
+    // once per device, serially: 8 x (41 + ~150) ms for the chess scene.)
+    const auto t0 = std::chrono::steady_clock::now();
+    HostBuild hb;
+    {
+        std::vector<std::thread> warm;
+        std::vector<double> warm_ms((size_t)n_devices, 0.0);
+        for (int i = 0; i < n_devices; ++i) {
+            bool first = true;
+            for (int j = 0; j < i; ++j) first = first && devices[j] != devices[i];
+            if (first) warm.emplace_back([&warm_ms, devices, i]() { warm_ms[(size_t)i] = warm_up_device(devices[i]); });
+        }
+        const int rc = build_scene_host(desc, nullptr, hb);
+        for (std::thread &t : warm) t.join();
         if (rc != MCPT_OK) {
             const std::string e = mcpt_last_error();
             mcpt_group_destroy(g);
-            return gfail(rc, "mcpt_group_create: device " + std::to_string(devices[i]) + ": " + e);
+            return gfail(rc, "mcpt_group_create: " + e);
         }
-        if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&g->streams[i], hipStreamNonBlocking) != hipSuccess) {
-            mcpt_group_destroy(g);
-            return gfail(MCPT_ERR_HIP, "mcpt_group_create: cannot create a stream");
-        }
+        for (double v : warm_ms) hb.init_ms = std::max(hb.init_ms, v);
     }
+    g->build_ms = hb.build_ms;
+    std::vector<int> rc((size_t)n_devices, MCPT_OK);
+    std::vector<std::string> err((size_t)n_devices);
+    auto up = [&](int i) {
+        HostBuild mine = hb;  // (upload_scene fills in what a device-side tree build returns: every thread works on its own copy)
+        rc[(size_t)i] = upload_scene(desc, mine, devices[i], &g->scenes[(size_t)i]);
+        if (rc[(size_t)i] != MCPT_OK) {
+            err[(size_t)i] = mcpt_last_error();
+            return;
+        }
+        if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&g->streams[(size_t)i], hipStreamNonBlocking) != hipSuccess) {
+            rc[(size_t)i] = MCPT_ERR_HIP;
+            err[(size_t)i] = "cannot create a stream";
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < n_devices; ++i) th.emplace_back(up, i);
+        up(0);
+        for (std::thread &t : th) t.join();
+    }
+    for (int i = 0; i < n_devices; ++i)
+        if (rc[(size_t)i] != MCPT_OK) {
+            const int code = rc[(size_t)i];
+            const std::string e = "mcpt_group_create: device " + std::to_string(devices[i]) + ": " + err[(size_t)i];
+            mcpt_group_destroy(g);
+            return gfail(code, e);
+        }
+    g->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out = g;
     return MCPT_OK;
 }
 
 int mcpt_group_size(const mcpt_group *g) { return g ? (int)g->scenes.size() : 0; }
+
+mcpt_scene *mcpt_group_scene(mcpt_group *g, int index) { return (g && index >= 0 && index < (int)g->scenes.size()) ? g->scenes[(size_t)index] : nullptr; }
+
+int mcpt_group_get_info(const mcpt_group *g, mcpt_group_info *info) {
+    if (!g || !info) return gfail(MCPT_ERR_ARG, "mcpt_group_get_info: null argument");
+    std::memset(info, 0, sizeof *info);
+    info->n_devices = (int32_t)g->scenes.size();
+    info->uses_rccl = g->same_device ? 0 : 1;
+    info->build_ms = g->build_ms;
+    info->setup_ms = g->setup_ms;
+    for (mcpt_scene *sc : g->scenes) {
+        mcpt_scene_info si;
+        if (sc && mcpt_scene_get_info(sc, &si) == MCPT_OK) {
+            info->upload_ms_max = std::max(info->upload_ms_max, si.upload_ms);
+            info->init_ms_max = std::max(info->init_ms_max, si.init_ms);
+        }
+    }
+    return MCPT_OK;
+}
 
 int mcpt_group_render(mcpt_group *g, const mcpt_camera *cam, const mcpt_params *pp, float *fb_host, mcpt_stats *stats) {
     if (!g || !cam || !pp || !fb_host) return gfail(MCPT_ERR_ARG, "mcpt_group_render: null argument");

@@ -17,7 +17,7 @@ CHECK_LIB_PATH = os.path.join(HERE, "libmcpt_hip_check.so")  # the checking buil
 
 EXPORTS = ["mcpt_scene_create", "mcpt_scene_destroy", "mcpt_render", "mcpt_render_device", "mcpt_intersect",
            "mcpt_cast_rays", "mcpt_camera_rays", "mcpt_scene_get_info", "mcpt_bvh_dump", "mcpt_scene_create_ex", "mcpt_scene_dump_bvh", "mcpt_tonemap", "mcpt_tonemap_device", "mcpt_debug_fmath", "mcpt_debug_material", "mcpt_debug_scene", "mcpt_debug_counters",
-           "mcpt_group_create", "mcpt_group_render", "mcpt_group_size", "mcpt_group_destroy", "mcpt_group_last_error",
+           "mcpt_group_create", "mcpt_group_render", "mcpt_group_size", "mcpt_group_get_info", "mcpt_group_scene", "mcpt_group_destroy", "mcpt_group_last_error",
            "mcpt_last_error", "mcpt_version"]
 
 
@@ -63,7 +63,12 @@ BUILDERS = {"default": 0, "sah": 1, "reference": 2, "lbvh": 3}  # MCPT_BUILD_*
 class SceneInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("bvh_height", C.c_int32), ("n_lights", C.c_int32), ("n_prims", C.c_int32),
                 ("scene_bytes", C.c_uint64), ("build_ms", C.c_double), ("upload_ms", C.c_double), ("builder", C.c_int32),
-                ("quantised", C.c_int32), ("n_instances", C.c_int32), ("lds_resident", C.c_int32)]
+                ("quantised", C.c_int32), ("n_instances", C.c_int32), ("lds_resident", C.c_int32), ("init_ms", C.c_double)]
+
+
+class GroupInfo(C.Structure):
+    _fields_ = [("n_devices", C.c_int32), ("uses_rccl", C.c_int32), ("build_ms", C.c_double), ("upload_ms_max", C.c_double),
+                ("init_ms_max", C.c_double), ("setup_ms", C.c_double)]
 
 
 _libs = {}
@@ -114,6 +119,10 @@ def lib(path=None):
         L.mcpt_group_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.mcpt_group_render.restype = C.c_int
         L.mcpt_group_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]
+        L.mcpt_group_get_info.restype = C.c_int
+        L.mcpt_group_get_info.argtypes = [C.c_void_p, C.POINTER(GroupInfo)]
+        L.mcpt_group_scene.restype = C.c_void_p
+        L.mcpt_group_scene.argtypes = [C.c_void_p, C.c_int]
         L.mcpt_group_size.restype = C.c_int
         L.mcpt_group_size.argtypes = [C.c_void_p]
         L.mcpt_group_destroy.restype = None
@@ -326,10 +335,10 @@ class HipScene:
 class HipGroup:
     """One replica of the scene per listed device; render() = mcpt_group_render (tile partition + RCCL merge inside the library)."""
 
-    def __init__(self, sd, devices):
+    def __init__(self, sd, devices, library=None):
         self.sd = sd
         self._keep = []
-        self.L = lib()
+        self.L = lib(library)
         d = _make_desc(sd, self._keep)
         dev = np.ascontiguousarray(devices, dtype=np.int32)
         h = C.c_void_p()
@@ -349,6 +358,13 @@ class HipGroup:
             self.close()
         except Exception:
             pass
+
+    def info(self):
+        i = GroupInfo()
+        rc = self.L.mcpt_group_get_info(self.h, C.byref(i))
+        if rc != 0:
+            raise McptError(rc, self.L.mcpt_group_last_error().decode("utf-8", "replace"))
+        return {k: getattr(i, k) for k, _ in i._fields_}
 
     def render(self, camera=None, fb=None, **kw):
         cam = np.ascontiguousarray(camera if camera is not None else self.sd.camera)

@@ -173,9 +173,23 @@ void Scene::buildBVH() {
     gpu = nullptr;
     mcpt_group_destroy(group);
     group = nullptr;
+    if (devices.size() > 1) {  // one replica per listed device; the tree is built once (mcpt_group_create)
+        if (mcpt_group_create(&d, (int)devices.size(), devices.data(), &group) != MCPT_OK) {
+            std::cerr << "mcpt: " << mcpt_group_last_error() << std::endl;
+            group = nullptr;
+            return;
+        }
+        mcpt_group_info gi;
+        if (mcpt_group_get_info(group, &gi) == MCPT_OK)
+            std::cout << "[mcpt] scene set-up on " << gi.n_devices << " GPU replicas: " << gi.setup_ms << " ms (tree built once: " << gi.build_ms
+                      << " ms; slowest upload " << gi.upload_ms_max << " ms; device start-up " << gi.init_ms_max << " ms beside the build)" << std::endl;
+        return;
+    }
     if (mcpt_scene_create(&d, devices.empty() ? -1 : devices[0], &gpu) != MCPT_OK) std::cerr << "mcpt: " << mcpt_last_error() << std::endl;
-    if (gpu && devices.size() > 1 && mcpt_group_create(&d, (int)devices.size(), devices.data(), &group) != MCPT_OK)
-        std::cerr << "mcpt: " << mcpt_group_last_error() << std::endl;
+    mcpt_scene_info si;
+    if (gpu && mcpt_scene_get_info(gpu, &si) == MCPT_OK)
+        std::cout << "[mcpt] scene set-up: build " << si.build_ms << " ms, upload " << si.upload_ms << " ms, device start-up " << si.init_ms
+                  << " ms beside the build" << std::endl;
 }
 
 mcpt_params Scene::params(int spp) const {

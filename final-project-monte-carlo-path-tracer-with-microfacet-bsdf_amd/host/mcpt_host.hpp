@@ -221,7 +221,7 @@ class Scene {
     float castRay(const Ray &ray, int depth, const WaveLenType &wavelen) const;  // Scene.cpp:85-184 (depth must be 0)
 
     // used by Renderer
-    mcpt_scene *handle() const { return gpu; }
+    mcpt_scene *handle() const { return group ? mcpt_group_scene(group, 0) : gpu; }  // (with several GPUs: the replica on the first one)
     // More than one entry: the frame is rendered by all listed GPUs (mcpt_group_*: tile partition + RCCL merge inside the
     // library; main() stays single-threaded).  Call before buildBVH.  {0, 0} rehearses the schedule on one GPU.
     void setDevices(const std::vector<int> &d) { devices = d; }

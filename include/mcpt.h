@@ -193,6 +193,17 @@ typedef struct mcpt_group mcpt_group;
 int mcpt_group_create(const mcpt_scene_desc *desc, int n_devices, const int *devices, mcpt_group **out);
 int mcpt_group_render(mcpt_group *group, const mcpt_camera *camera, const mcpt_params *params, float *fb_host, mcpt_stats *stats);
 int mcpt_group_size(const mcpt_group *group);
+/* What mcpt_group_create spent: the scene is flattened and its tree built once (build_ms) while every device is brought up on a helper
+ * thread (init_ms_max), then one thread per device copies it (upload_ms_max); setup_ms is the wall clock of the whole call. */
+typedef struct {
+    int32_t n_devices;
+    int32_t uses_rccl; /* 1: distinct devices, the frames are merged by one ncclReduce; 0: every entry names one device (rehearsal) */
+    double build_ms, upload_ms_max, init_ms_max, setup_ms;
+} mcpt_group_info;
+int mcpt_group_get_info(const mcpt_group *group, mcpt_group_info *info);
+/* The replica on the index-th device of the group (borrowed: it lives as long as the group), for calls that take a scene, e.g.
+ * mcpt_tonemap after mcpt_group_render.  NULL when out of range. */
+mcpt_scene *mcpt_group_scene(mcpt_group *group, int index);
 void mcpt_group_destroy(mcpt_group *group);
 const char *mcpt_group_last_error(void);
 
@@ -206,6 +217,8 @@ typedef struct {
     int32_t quantised;/* 1: 32-byte nodes with 16-bit boxes are traversed */
     int32_t n_instances; /* objects whose traversal nodes are shared with a prototype (0: plain tree) */
     int32_t lds_resident; /* 1: the scene is small enough for the kernels that copy nodes, triangles, spheres and light tables into LDS */
+    double init_ms;   /* first use of the device by this process (context creation, load of the library's code objects), run on a helper
+                         thread beside the host build; ~0 for every later scene.  Not part of build_ms / upload_ms */
 } mcpt_scene_info;
 int mcpt_scene_get_info(const mcpt_scene *scene, mcpt_scene_info *info);
 

@@ -34,19 +34,36 @@ def test_group_rehearsal_is_bit_identical_to_one_gpu(pkg, hip):
         g.close()
 
 
-def test_rccl_merge_path_with_a_communicator_of_one(pkg, hip, monkeypatch):
+def test_rccl_merge_path_with_a_communicator_of_one(pkg, hip, hip_check, monkeypatch):
     """The RCCL leg of mcpt_group_render (dlopen of librccl, ncclCommInitAll, ncclGroupStart / ncclReduce / ncclGroupEnd on the group's
-    stream) needs distinct devices; MCPT_GROUP_FORCE_RCCL=1 runs it for a group of ONE device (a one-rank communicator), which is what a
-    one-GPU box can exercise of it.  The frame must be the plain one."""
+    stream) needs distinct devices.  The CHECKING build has a test hook for it, MCPT_GROUP_FORCE_RCCL=1: a group of ONE device goes through
+    a one-rank communicator, which is what a one-GPU box can exercise of that leg.  The frame must be the plain one; the product library
+    has no such hook (it ignores the variable)."""
     sd = pkg.scenes.cornell_demo(64, 48, 4)
     ref, _ = hip.HipScene(sd).render(spp=4, seed=2)
     monkeypatch.setenv("MCPT_GROUP_FORCE_RCCL", "1")
-    g = hip.HipGroup(sd, [0])
+    g = hip.HipGroup(sd, [0], library=hip_check)
+    assert g.info()["uses_rccl"] == 1
     fb, st = g.render(spp=4, seed=2)
     assert np.array_equal(ref, fb, equal_nan=True) and st.samples == 64 * 48 * 4
     fb2, _ = g.render(fb=fb.copy(), spp=4, spp_total=8, sample_offset=4, accumulate=1, seed=2)  # the communicator is reused
     assert np.isfinite(fb2).all()
     g.close()
+    g = hip.HipGroup(sd, [0])  # the product build
+    assert g.info()["uses_rccl"] == 0
+    g.close()
+
+
+def test_group_builds_the_tree_once(pkg, hip):
+    """mcpt_group_create flattens the scene and builds its tree once, then uploads from one thread per device: the set-up of four replicas
+    costs about one build, not four (round 2: a build per device, serially)."""
+    sd = pkg.scenes.chess_scene(width=64, height=36, spp=1)
+    one = hip.HipGroup(sd, [0]).info()
+    four = hip.HipGroup(sd, [0, 0, 0, 0]).info()
+    print("\n[group] set-up of 1 replica: %.1f ms (build %.1f, upload %.1f, device init %.1f); of 4 replicas: %.1f ms (build %.1f, slowest upload %.1f)"
+          % (one["setup_ms"], one["build_ms"], one["upload_ms_max"], one["init_ms_max"], four["setup_ms"], four["build_ms"], four["upload_ms_max"]))
+    assert four["n_devices"] == 4 and four["build_ms"] < 2.5 * max(one["build_ms"], 20.0)
+    assert four["setup_ms"] < 2.0 * four["build_ms"] + 4 * max(four["upload_ms_max"], 5.0) + 100.0
 
 
 def test_group_argument_errors(pkg, hip):
