@@ -245,6 +245,7 @@ struct Timer {
 
 struct mcpt_scene {
     int device = 0;
+    int device_sharers = 1;  // scenes of one group that live on this device (mcpt_group_create with a device listed several times)
     int32_t n_inner = 0;  // inner nodes of the traversal tree (0: the root is a leaf)
     Knobs knobs;
     mcpt_scene_info info{};
@@ -723,7 +724,10 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
             launch_sky_fill(sh.culled_list.p + n_trace, n_pix_owned - n_trace, sc->view.background, p.spp, spp_total, fb_dev, st);
             n_pix = n_trace;
             pixel_list = sh.culled_list.p;
-            pixel_cand = sh.cand_list.p;
+            // (candidate lists skip the float box tests of a primitive's ancestors: a ray that grazes a box face within rounding is a hit
+            // through the list and a miss through the tree.  With the reference's own topology the kernels promise the reference's box
+            // semantics exactly, so primary rays walk the tree there; the sky cull itself stays.)
+            pixel_cand = sc->info.builder == 1 ? nullptr : sh.cand_list.p;
         }
     }
 
@@ -731,7 +735,9 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     while ((uint64_t)n_pix * s_pass_req * 3ull > 0xfffffff0ull && s_pass_req > 1) s_pass_req /= 2;
     const int s_pass = std::min(s_pass_req, p.spp);
     const int max_depth = derive_max_depth(p);
-    uint64_t pool64 = p.pool_paths > 0 ? (uint64_t)p.pool_paths : (60ull << 20);  // measured (round 2): 28 Mi 4467, 40 Mi 4557, 60 Mi 4617, 80 Mi 4605 Msamples/s
+    // default: the smallest pool within 1 % of the best rate.  Measured on the chess frame (round 3, A/B on one box): 40 Mi paths 5031-5045,
+    // 48 Mi 5061, 60 Mi 5052-5066 Msamples/s (round 2: 28 Mi 4467, 40 Mi 4557, 60 Mi 4617, 80 Mi 4605); 40 Mi paths are 38 GB of workspace
+    uint64_t pool64 = p.pool_paths > 0 ? (uint64_t)p.pool_paths : (40ull << 20);
     pool64 = std::max<uint64_t>(pool64, 3 * 256);
     // keep the clamp stack within 48 GiB
     while (pool64 * (uint64_t)max_depth * 16ull > (48ull << 30) && pool64 > 3 * 4096) pool64 /= 2;
@@ -747,7 +753,10 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
             uint64_t held = 0;
             for (int k = 0; k < mcpt_scene::kMaxPools; ++k) held += (uint64_t)sc->pools[k].ws.pool * bytes_per_pool_path(sc->pools[k].ws.n_dir, sc->pools[k].ws.max_depth);
             const uint64_t result_b = (uint64_t)n_pix * s_pass_req * 3ull * 4ull * 2ull;
-            const uint64_t have = (uint64_t)free_b + held + sc->shared.result.bytes();
+            uint64_t have = (uint64_t)free_b + held + sc->shared.result.bytes();
+            // replicas of one group that share this device (a rehearsal on a one-GPU box) size their pools at the same time, each
+            // from the same "free" figure: every one of them may take its share only
+            have /= (uint64_t)std::max(1, sc->device_sharers);
             const uint64_t budget = have * 8 / 10 > result_b ? have * 8 / 10 - result_b : 0;
             const uint64_t per = bytes_per_pool_path(p.n_dir_sample, max_depth);
             while (pool64 * per > budget && pool64 > 3 * 4096) pool64 /= 2;
@@ -932,7 +941,7 @@ int build_scene_host(const mcpt_scene_desc *desc, const mcpt_build_options *opti
     const auto t_build = std::chrono::steady_clock::now();
     hb.choice = resolve_build_choice(options);
     // (a single primitive has no inner node: nothing for the device builder to do)
-    if (hb.choice.builder == MCPT_BUILD_GPU_LBVH && desc->objects) {
+    if ((hb.choice.builder == MCPT_BUILD_GPU_LBVH || hb.choice.builder == MCPT_BUILD_GPU_PLOC) && desc->objects) {
         int64_t n_prim = desc->n_triangles;
         for (int i = 0; i < desc->n_objects; ++i) n_prim += desc->objects[i].kind == MCPT_OBJ_SPHERE ? 1 : 0;
         if (n_prim < 2) hb.choice.builder = MCPT_BUILD_SAH;
@@ -1003,7 +1012,7 @@ int upload_scene(const mcpt_scene_desc *desc, HostBuild &hb, int device, mcpt_sc
     auto up = [&](auto &buf, const auto &vec) {
         if (e == hipSuccess) e = upload(buf, vec);
     };
-    if (hs.builder != 2) {
+    if (hs.builder < 2) {
         up(sc->nodes, hs.nodes);
         if (!hs.qnodes.empty()) up(sc->qnodes, hs.qnodes);
     }
@@ -1021,7 +1030,7 @@ int upload_scene(const mcpt_scene_desc *desc, HostBuild &hb, int device, mcpt_sc
         return fail(e == hipErrorOutOfMemory ? MCPT_ERR_OOM : MCPT_ERR_HIP, std::string("scene upload: ") + hipGetErrorString(e));
     }
     double gpu_build_ms = 0.0;
-    if (hs.builder == 2) {  // the traversal tree is built on the device from the caller's triangles (csrc/mcpt_lbvh.hip)
+    if (hs.builder >= 2) {  // the traversal tree is built on the device from the caller's triangles (csrc/mcpt_lbvh.hip)
         const auto tb = std::chrono::steady_clock::now();
         const int n_sph = (int)hs.sphere_objects.size();
         const int n_prim = hs.n_triangles + n_sph;
@@ -1033,7 +1042,8 @@ int upload_scene(const mcpt_scene_desc *desc, HostBuild &hb, int device, mcpt_sc
         if (e == hipSuccess) e = sc->nodes.alloc((size_t)n_prim - 1);
         if (e == hipSuccess) e = sc->qnodes.alloc((size_t)n_prim - 1);
         LbvhResult R;
-        if (e == hipSuccess) e = build_lbvh_device(d_tris.p, hs.n_triangles, d_sph.p, sc->spheres.p, n_sph, choice.quantise, sc->nodes.p, sc->qnodes.p, &R, nullptr);
+        if (e == hipSuccess) e = build_lbvh_device(d_tris.p, hs.n_triangles, d_sph.p, sc->spheres.p, n_sph, choice.quantise, hs.builder == 3 ? 1 : 0, choice.ploc_radius, choice.ploc_top,
+                                                 sc->nodes.p, sc->qnodes.p, &R, nullptr);
         if (e != hipSuccess) {
             mcpt_scene_destroy(sc);
             return fail(e == hipErrorOutOfMemory ? MCPT_ERR_OOM : MCPT_ERR_HIP, std::string("GPU BVH build: ") + hipGetErrorString(e));
@@ -1177,7 +1187,8 @@ int mcpt_bvh_dump(const mcpt_scene_desc *desc, mcpt_bvh_info *info, float *boxes
     HostScene hs;
     const char *err = "";
     const BuildChoice choice = resolve_build_choice(nullptr);
-    if (choice.builder == MCPT_BUILD_GPU_LBVH) return fail(MCPT_ERR_ARG, "mcpt_bvh_dump: the tree is built on the device (MCPT_BVH=lbvh): use mcpt_scene_dump_bvh");
+    if (choice.builder == MCPT_BUILD_GPU_LBVH || choice.builder == MCPT_BUILD_GPU_PLOC)
+        return fail(MCPT_ERR_ARG, "mcpt_bvh_dump: the tree is built on the device (MCPT_BVH=lbvh / ploc): use mcpt_scene_dump_bvh");
     const int rc = build_host_scene(*desc, hs, &err, choice);
     if (rc != MCPT_OK) return fail(rc, std::string("mcpt_bvh_dump: ") + err);
     std::memset(info, 0, sizeof *info);
@@ -1279,6 +1290,14 @@ int mcpt_scene_dump_bvh(mcpt_scene *sc, mcpt_bvh_info *info, float *boxes, int32
     }
     return MCPT_OK;
 }
+
+}  // extern "C"
+namespace mcpt {
+void set_device_sharers(mcpt_scene *sc, int n) {
+    if (sc) sc->device_sharers = n > 0 ? n : 1;
+}
+}  // namespace mcpt
+extern "C" {
 
 int mcpt_scene_get_info(const mcpt_scene *sc, mcpt_scene_info *info) {
     if (!sc || !info) return fail(MCPT_ERR_ARG, "mcpt_scene_get_info: null argument");

@@ -143,7 +143,7 @@ struct HostScene {
     int32_t root;                         // root child reference (inner index or leaf)
     int32_t n_triangles = 0, n_objects = 0;
     int32_t height = 0;
-    int32_t builder = 0;                  // 0 host binned SAH, 1 host reference topology, 2 GPU LBVH (mcpt_scene_info::builder)
+    int32_t builder = 0;                  // 0 host binned SAH, 1 host reference topology, 2 GPU LBVH, 3 GPU PLOC (mcpt_scene_info::builder)
     std::vector<int32_t> sphere_objects;  // object index of every sphere object (the GPU builder's primitive list)
     std::vector<InstRec> instances;       // instanced objects (empty: plain single-level tree); leaf reference ~(n_leaf_prims + k)
     int32_t n_leaf_prims = 0;             // n_triangles + n_objects: leaf indices below it are primitives, from it on instances
@@ -157,13 +157,20 @@ struct HostScene {
 
 // Builder choice after the environment overrides have been applied (mcpt_build_options, include/mcpt.h).
 struct BuildChoice {
-    int32_t builder = MCPT_BUILD_SAH;  // MCPT_BUILD_SAH | MCPT_BUILD_REFERENCE | MCPT_BUILD_GPU_LBVH
+    int32_t builder = MCPT_BUILD_SAH;  // MCPT_BUILD_SAH | MCPT_BUILD_REFERENCE | MCPT_BUILD_GPU_LBVH | MCPT_BUILD_GPU_PLOC
     int32_t quantise = -1;             // -1 automatic, 0 never, 1 always
     int32_t instancing = -1;           // -1 automatic (large scenes with repeated meshes), 0 never, 1 whenever a mesh repeats
+    int32_t ploc_radius = 16;          // MCPT_BUILD_GPU_PLOC: clusters searched on either side (MCPT_PLOC_RADIUS)
+    int32_t ploc_top = 16384;          // ... and the cluster count at which the host's binned SAH takes over (MCPT_PLOC_TOP; 0: never;
+                                       // at most a sixteenth of the primitives)
 };
 BuildChoice resolve_build_choice(const mcpt_build_options *opt);
 
-// Builds the flattened scene.  Returns MCPT_OK or an error code and fills `err`.  With MCPT_BUILD_GPU_LBVH the traversal tree is left
+// Binned-SAH top of a tree over the clusters a device builder stopped at (csrc/mcpt_scene.cpp; used by the PLOC builder).
+void build_sah_over_clusters(int m, const float *cmin4, const float *cmax4, const int32_t *cref, const int32_t *clevels, int node_base,
+                             std::vector<Node> &out, int32_t &root_ref, int32_t &height);
+
+// Builds the flattened scene.  Returns MCPT_OK or an error code and fills `err`.  With MCPT_BUILD_GPU_LBVH / _PLOC the traversal tree is left
 // out (nodes empty, root/height unset): the caller builds it on the device (csrc/mcpt_lbvh.hip); everything else is filled.
 int build_host_scene(const mcpt_scene_desc &d, HostScene &out, const char **err, const BuildChoice &choice);
 

@@ -174,6 +174,7 @@ struct HostBuild {
 int build_scene_host(const mcpt_scene_desc *desc, const mcpt_build_options *options, HostBuild &hb);
 int upload_scene(const mcpt_scene_desc *desc, HostBuild &hb, int device, mcpt_scene **out);
 double warm_up_device(int device);
+void set_device_sharers(mcpt_scene *sc, int n);  // replicas of a group on one device divide its free memory between them
 
 void launch_init_free(uint32_t *free_slots, Counters *c, uint32_t pool, uint32_t start, uint32_t mask, hipStream_t s);
 // After k_shade(cur -> next): adds this iteration's list lengths to the cumulative totals and clears the counters of

@@ -18,8 +18,10 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "mcpt_lbvh.h"
 
@@ -248,6 +250,120 @@ __global__ __launch_bounds__(kB) void k_quantise(int n_nodes, const Node *__rest
     qn[i] = Q;
 }
 
+// ------------------------------------------------------------------------------------------------
+// PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) on the Morton-sorted primitives -- the builder for trees of (near)
+// SAH quality built on the device.  Bottom-up: the clusters (at first one leaf per primitive, in Morton order) look for their nearest
+// neighbour -- the one whose union box has the smallest surface area -- among the kRadius clusters before and after them in the
+// array; mutual nearest neighbours are merged into a new inner node, the array is compacted (order preserved), and the round repeats until
+// one cluster is left.  Unlike the Karras hierarchy, whose splits follow the bits of the codes, every merge is chosen by surface area, which
+// is what the SAH measures.  Each round is three small kernels and a scan; the number of clusters falls by 35-45 % per round.
+//   k_ploc_init    cluster i = leaf of the primitive at sorted position i
+//   k_ploc_nn      nearest neighbour within +-radius (boxes staged through LDS; ties -> the smaller index, which guarantees a mutual pair)
+//   k_ploc_flags   keep / merge decision per cluster: {stays in the array, creates a node}
+//   hipcub scan    positions in the compacted array and indices of the new nodes
+//   k_ploc_emit    writes the new nodes (both child boxes, child references) and the next round's cluster array
+// ------------------------------------------------------------------------------------------------
+constexpr int kPlocMaxRadius = 64;
+struct PlocArrays {
+    float4 *bmin, *bmax;  // cluster boxes
+    int32_t *ref;         // >= 0: inner node index; < 0: ~(global primitive id)
+    int32_t *levels;      // levels of the cluster's subtree (a leaf: 1)
+};
+
+__global__ __launch_bounds__(kB) void k_ploc_init(int n, BuildScratch S, PlocArrays C) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = S.vals_sorted[i];
+    C.bmin[i] = make_float4(S.pmin[3 * p], S.pmin[3 * p + 1], S.pmin[3 * p + 2], 0.f);
+    C.bmax[i] = make_float4(S.pmax[3 * p], S.pmax[3 * p + 1], S.pmax[3 * p + 2], 0.f);
+    C.ref[i] = ~S.prim_id[p];
+    C.levels[i] = 1;
+    const float dx = S.pmax[3 * p] - S.pmin[3 * p], dy = S.pmax[3 * p + 1] - S.pmin[3 * p + 1], dz = S.pmax[3 * p + 2] - S.pmin[3 * p + 2];
+    atomicAdd(S.diag_sum, (double)sqrtf(dx * dx + dy * dy + dz * dz));  // (mean leaf diagonal: the quantisation rule below)
+}
+
+__device__ __forceinline__ float union_half_area(float4 amin, float4 amax, float4 bmin, float4 bmax) {
+    const float dx = fmaxf(amax.x, bmax.x) - fminf(amin.x, bmin.x), dy = fmaxf(amax.y, bmax.y) - fminf(amin.y, bmin.y),
+                dz = fmaxf(amax.z, bmax.z) - fminf(amin.z, bmin.z);
+    return dx * dy + (dy * dz + dz * dx);
+}
+
+__global__ __launch_bounds__(kB) void k_ploc_nn(int m, int radius, PlocArrays C, int32_t *__restrict__ nn) {
+    __shared__ float4 smin[kB + 2 * kPlocMaxRadius], smax[kB + 2 * kPlocMaxRadius];
+    const int base = blockIdx.x * kB;
+    for (int t = threadIdx.x; t < kB + 2 * radius; t += kB) {
+        const int j = base - radius + t;
+        if (j >= 0 && j < m) {
+            smin[t] = C.bmin[j];
+            smax[t] = C.bmax[j];
+        }
+    }
+    __syncthreads();
+    const int i = base + threadIdx.x;
+    if (i >= m) return;
+    const float4 mn = smin[threadIdx.x + radius], mx = smax[threadIdx.x + radius];
+    float best = INFINITY;
+    int bj = -1;
+    for (int d = -radius; d <= radius; ++d) {  // ascending j: a tie keeps the smaller index
+        const int j = i + d;
+        if (d == 0 || j < 0 || j >= m) continue;
+        const float a = union_half_area(mn, mx, smin[threadIdx.x + radius + d], smax[threadIdx.x + radius + d]);
+        if (a < best || bj < 0) {
+            best = a;
+            bj = j;
+        }
+    }
+    nn[i] = bj;
+}
+
+// flags[i] = {1: cluster i stays in the array (alone, or as the new node of its pair)} | {1: it creates a node} << 32
+__global__ __launch_bounds__(kB) void k_ploc_flags(int m, const int32_t *__restrict__ nn, unsigned long long *__restrict__ flags) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= m) return;
+    const int j = nn[i];
+    const bool mutual = j >= 0 && nn[j] == i;
+    const unsigned long long stays = (mutual && i > j) ? 0ull : 1ull, creates = (mutual && i < j) ? 1ull : 0ull;
+    flags[i] = stays | (creates << 32);
+}
+
+__global__ __launch_bounds__(kB) void k_ploc_emit(int m, int node_base, const int32_t *__restrict__ nn, const unsigned long long *__restrict__ flags,
+                                                  const unsigned long long *__restrict__ scan, PlocArrays in, PlocArrays out, Node *__restrict__ nodes,
+                                                  uint32_t *__restrict__ totals) {
+    const int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= m) return;
+    const unsigned long long f = flags[i], s = scan[i];
+    if (i == m - 1) {
+        totals[0] = (uint32_t)s + (uint32_t)(f & 1ull);        // clusters of the next round
+        totals[1] = (uint32_t)(s >> 32) + (uint32_t)(f >> 32);  // nodes created in this round
+    }
+    if (!(f & 1ull)) return;
+    const uint32_t pos = (uint32_t)s;
+    float4 mn = in.bmin[i], mx = in.bmax[i];
+    int32_t ref = in.ref[i], lv = in.levels[i];
+    if (f >> 32) {
+        const int j = nn[i];
+        const float4 jmn = in.bmin[j], jmx = in.bmax[j];
+        const int node = node_base + (int)(uint32_t)(s >> 32);
+        Node N;
+        N.lmin[0] = mn.x, N.lmin[1] = mn.y, N.lmin[2] = mn.z;
+        N.lmax[0] = mx.x, N.lmax[1] = mx.y, N.lmax[2] = mx.z;
+        N.rmin[0] = jmn.x, N.rmin[1] = jmn.y, N.rmin[2] = jmn.z;
+        N.rmax[0] = jmx.x, N.rmax[1] = jmx.y, N.rmax[2] = jmx.z;
+        N.left = ref;
+        N.right = in.ref[j];
+        N.pad[0] = N.pad[1] = 0;
+        nodes[node] = N;
+        mn = make_float4(fminf(mn.x, jmn.x), fminf(mn.y, jmn.y), fminf(mn.z, jmn.z), 0.f);
+        mx = make_float4(fmaxf(mx.x, jmx.x), fmaxf(mx.y, jmx.y), fmaxf(mx.z, jmx.z), 0.f);
+        ref = node;
+        lv = 1 + max(lv, in.levels[j]);
+    }
+    out.bmin[pos] = mn;
+    out.bmax[pos] = mx;
+    out.ref[pos] = ref;
+    out.levels[pos] = lv;
+}
+
 template <typename T>
 hipError_t dalloc(T *&p, size_t count) {
     p = nullptr;
@@ -257,7 +373,7 @@ hipError_t dalloc(T *&p, size_t count) {
 }  // namespace
 
 hipError_t build_lbvh_device(const mcpt_triangle *d_tris, int n_tri, const int32_t *d_sphere_obj, const SphereRec *d_spheres, int n_sph,
-                             int quantise, Node *d_nodes, QNode *d_qnodes, LbvhResult *out, hipStream_t st) {
+                             int quantise, int algo, int ploc_radius, int ploc_top, Node *d_nodes, QNode *d_qnodes, LbvhResult *out, hipStream_t st) {
     const int n = n_tri + n_sph;
     std::memset(out, 0, sizeof *out);
     if (n < 2) return hipErrorInvalidValue;
@@ -308,20 +424,100 @@ hipError_t build_lbvh_device(const mcpt_triangle *d_tris, int n_tri, const int32
             cinv.z = cmax.z > cmin.z ? 1.0f / (cmax.z - cmin.z) : 0.f;
             hipLaunchKernelGGL(k_morton, dim3(nblocks(n)), dim3(kB), 0, st, n, cmin, cinv, S);
             chk(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, S.keys, S.keys_sorted, S.vals, S.vals_sorted, n, 0, 63, st));
-            hipLaunchKernelGGL(k_hierarchy, dim3(nblocks(n - 1)), dim3(kB), 0, st, n, S);
-            hipLaunchKernelGGL(k_refit, dim3(nblocks(n)), dim3(kB), 0, st, n, S, d_nodes);
-            hipLaunchKernelGGL(k_depth, dim3(nblocks(n)), dim3(kB), 0, st, n, S);
             float rb[6];
             double diag = 0;
-            int32_t h = 0;
-            chk(hipMemcpyAsync(rb, S.nmin, 3 * sizeof(float), hipMemcpyDeviceToHost, st));      // inner node 0 is the root
-            chk(hipMemcpyAsync(rb + 3, S.nmax, 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+            int32_t h = 0, root = 0;
+            if (algo == 0) {
+                hipLaunchKernelGGL(k_hierarchy, dim3(nblocks(n - 1)), dim3(kB), 0, st, n, S);
+                hipLaunchKernelGGL(k_refit, dim3(nblocks(n)), dim3(kB), 0, st, n, S, d_nodes);
+                hipLaunchKernelGGL(k_depth, dim3(nblocks(n)), dim3(kB), 0, st, n, S);
+                chk(hipMemcpyAsync(rb, S.nmin, 3 * sizeof(float), hipMemcpyDeviceToHost, st));      // inner node 0 is the root
+                chk(hipMemcpyAsync(rb + 3, S.nmax, 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+                chk(hipMemcpyAsync(&h, S.height, sizeof h, hipMemcpyDeviceToHost, st));
+            } else {
+                // ---- PLOC rounds (see k_ploc_*)
+                const int radius = std::min(std::max(ploc_radius, 1), kPlocMaxRadius);
+                PlocArrays C[2];
+                std::memset(C, 0, sizeof C);
+                int32_t *nn = nullptr;
+                unsigned long long *flags = nullptr, *scan = nullptr;
+                uint32_t *totals = nullptr;
+                void *scan_temp = nullptr;
+                size_t scan_bytes = 0;
+                for (int k = 0; k < 2; ++k) {
+                    chk(dalloc(C[k].bmin, n));
+                    chk(dalloc(C[k].bmax, n));
+                    chk(dalloc(C[k].ref, n));
+                    chk(dalloc(C[k].levels, n));
+                }
+                chk(dalloc(nn, n));
+                chk(dalloc(flags, n));
+                chk(dalloc(scan, n));
+                chk(dalloc(totals, 2));
+                if (e == hipSuccess) chk(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags, scan, n, st));
+                if (e == hipSuccess) chk(hipMalloc(&scan_temp, scan_bytes ? scan_bytes : 1));
+                int m = n, node_base = 0, cur = 0, rounds = 0;
+                // the rounds stop at `top` clusters; the tree above them is a binned-SAH build on the host (build_sah_over_clusters): a few
+                // thousand boxes, a millisecond or two.  Scenes too small for that are merged down to the root here.
+                // Measured (frame rate against the host SAH tree's, A/B on one box): 296 k triangles: no top -3.8 %, 4096 clusters -2.2 %,
+                // 16384 -1.6 %; 38 k triangles: no top -6.5 %, 1024 -6.2 %.
+                int top = std::min(ploc_top, n / 16);
+                if (top < 64) top = 1;
+                if (e == hipSuccess) hipLaunchKernelGGL(k_ploc_init, dim3(nblocks(n)), dim3(kB), 0, st, n, S, C[0]);
+                while (e == hipSuccess && m > top) {
+                    hipLaunchKernelGGL(k_ploc_nn, dim3(nblocks(m)), dim3(kB), 0, st, m, radius, C[cur], nn);
+                    hipLaunchKernelGGL(k_ploc_flags, dim3(nblocks(m)), dim3(kB), 0, st, m, nn, flags);
+                    chk(hipcub::DeviceScan::ExclusiveSum(scan_temp, scan_bytes, flags, scan, m, st));
+                    hipLaunchKernelGGL(k_ploc_emit, dim3(nblocks(m)), dim3(kB), 0, st, m, node_base, nn, flags, scan, C[cur], C[cur ^ 1], d_nodes, totals);
+                    uint32_t tot[2] = {0, 0};
+                    chk(hipMemcpyAsync(tot, totals, sizeof tot, hipMemcpyDeviceToHost, st));
+                    chk(hipStreamSynchronize(st));
+                    if (e != hipSuccess) break;
+                    if ((int)tot[0] >= m || tot[1] == 0) {  // (cannot happen: the closest pair of the array is always mutual)
+                        e = hipErrorUnknown;
+                        break;
+                    }
+                    m = (int)tot[0];
+                    node_base += (int)tot[1];
+                    cur ^= 1;
+                    ++rounds;
+                }
+                if (e == hipSuccess) {
+                    std::vector<float4> bmn((size_t)m), bmx((size_t)m);
+                    std::vector<int32_t> cref((size_t)m), clev((size_t)m);
+                    chk(hipMemcpyAsync(bmn.data(), C[cur].bmin, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, st));
+                    chk(hipMemcpyAsync(bmx.data(), C[cur].bmax, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, st));
+                    chk(hipMemcpyAsync(clev.data(), C[cur].levels, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                    chk(hipMemcpyAsync(cref.data(), C[cur].ref, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                    chk(hipStreamSynchronize(st));
+                    if (e == hipSuccess) {
+                        root = cref[0];
+                        h = clev[0];
+                        if (m > 1) {  // the top of the tree: SAH over the remaining clusters
+                            std::vector<Node> topn;
+                            build_sah_over_clusters(m, &bmn[0].x, &bmx[0].x, cref.data(), clev.data(), node_base, topn, root, h);
+                            chk(hipMemcpyAsync(d_nodes + node_base, topn.data(), topn.size() * sizeof(Node), hipMemcpyHostToDevice, st));
+                            chk(hipStreamSynchronize(st));
+                            node_base += (int)topn.size();
+                        }
+                        for (int a = 0; a < 3; ++a) rb[a] = INFINITY, rb[3 + a] = -INFINITY;
+                        for (int i = 0; i < m; ++i) {
+                            rb[0] = fminf(rb[0], bmn[(size_t)i].x), rb[1] = fminf(rb[1], bmn[(size_t)i].y), rb[2] = fminf(rb[2], bmn[(size_t)i].z);
+                            rb[3] = fmaxf(rb[3], bmx[(size_t)i].x), rb[4] = fmaxf(rb[4], bmx[(size_t)i].y), rb[5] = fmaxf(rb[5], bmx[(size_t)i].z);
+                        }
+                    }
+                }
+                if (e == hipSuccess && node_base != n - 1) e = hipErrorUnknown;
+                out->rounds = rounds;
+                for (void *p : {(void *)C[0].bmin, (void *)C[0].bmax, (void *)C[0].ref, (void *)C[0].levels, (void *)C[1].bmin, (void *)C[1].bmax,
+                                (void *)C[1].ref, (void *)C[1].levels, (void *)nn, (void *)flags, (void *)scan, (void *)totals, scan_temp})
+                    if (p) (void)hipFree(p);
+            }
             chk(hipMemcpyAsync(&diag, S.diag_sum, sizeof diag, hipMemcpyDeviceToHost, st));
-            chk(hipMemcpyAsync(&h, S.height, sizeof h, hipMemcpyDeviceToHost, st));
             chk(hipStreamSynchronize(st));
             chk(hipGetLastError());
             if (e == hipSuccess) {
-                out->root = 0;
+                out->root = root;
                 out->height = h;
                 out->n_nodes = n - 1;
                 for (int a = 0; a < 3; ++a) {

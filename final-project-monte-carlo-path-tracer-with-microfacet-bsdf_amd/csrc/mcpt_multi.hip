@@ -188,6 +188,11 @@ int mcpt_group_create(const mcpt_scene_desc *desc, int n_devices, const int *dev
             mcpt_group_destroy(g);
             return gfail(code, e);
         }
+    for (int i = 0; i < n_devices; ++i) {
+        int sharers = 0;
+        for (int j = 0; j < n_devices; ++j) sharers += devices[j] == devices[i] ? 1 : 0;
+        set_device_sharers(g->scenes[(size_t)i], sharers);
+    }
     g->setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *out = g;
     return MCPT_OK;

@@ -16,6 +16,13 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <thread>
+#ifdef __linux__
+#include <sched.h>
+#endif
 
 #include "mcpt_internal.h"
 
@@ -69,11 +76,32 @@ struct BNode {  // BVHBuildNode, BVH.hpp:53-69
 
 struct Arena {
     std::vector<std::unique_ptr<BNode>> nodes;
+    std::mutex mu;  // sah_build hands subtrees to helper threads
     BNode *make() {
-        nodes.emplace_back(new BNode());
-        return nodes.back().get();
+        BNode *n = new BNode();
+        std::lock_guard<std::mutex> lock(mu);
+        nodes.emplace_back(n);
+        return n;
     }
 };
+
+// Helper threads of the binned-SAH build: the two halves of a split are independent, so big subtrees are built side by side.  The
+// tree does not depend on how many helpers there are (disjoint ranges, the flattened order comes from the tree, not from the arena).
+// MCPT_BUILD_THREADS (default: the CPUs this process may run on, at most 16; 1 = the sequential build).
+std::atomic<int> g_spare_builders{-1};
+int build_threads() {
+    if (const char *v = std::getenv("MCPT_BUILD_THREADS")) return std::max(1, std::atoi(v));
+    int n = (int)std::thread::hardware_concurrency();
+#ifdef __linux__
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+#endif
+    return std::min(std::max(n, 1), 16);
+}
+void init_builders() {  // once per process (the helpers are a process-wide budget, shared by scenes built concurrently)
+    int expect = -1;
+    g_spare_builders.compare_exchange_strong(expect, build_threads() - 1);
+}
 
 BNode *recursive_build(Arena &A, std::vector<BObj *> objs) {  // BVH.cpp:27-93
     BNode *node = A.make();
@@ -182,8 +210,22 @@ BNode *sah_build(Arena &A, std::vector<BObj *> &objs, size_t begin, size_t end) 
         mid = (size_t)(it - objs.begin());
         if (mid == begin || mid == end) mid = begin + n / 2;
     }
-    node->left = sah_build(A, objs, begin, mid);
-    node->right = sah_build(A, objs, mid, end);
+    // (a helper for the left half when both halves are big and one is free; the counter never goes below zero)
+    bool helper = false;
+    if (mid - begin >= 4096 && end - mid >= 4096) {
+        int spare = g_spare_builders.load();
+        while (spare > 0 && !g_spare_builders.compare_exchange_weak(spare, spare - 1)) {}
+        helper = spare > 0;
+    }
+    if (helper) {
+        std::thread t([&]() { node->left = sah_build(A, objs, begin, mid); });
+        node->right = sah_build(A, objs, mid, end);
+        t.join();
+        g_spare_builders.fetch_add(1);
+    } else {
+        node->left = sah_build(A, objs, begin, mid);
+        node->right = sah_build(A, objs, mid, end);
+    }
     node->bounds = box_union(node->left->bounds, node->right->bounds);
     node->area = node->left->area + node->right->area;
     return node;
@@ -445,6 +487,52 @@ struct Flattener {
 
 }  // namespace
 
+// The top of a tree over `m` clusters -- the subtrees a device builder (PLOC, csrc/mcpt_lbvh.hip) stopped at -- built with the binned
+// SAH of this file: top-down splits separate space better than bottom-up merges do near the root, where near-first traversal and
+// the pruning by the closest hit gain most.  cmin4 / cmax4: m boxes as float4; cref: the child reference of each cluster as it goes
+// into Node::left / right; clevels: levels of its subtree (a leaf: 1).  Appends m - 1 nodes to `out`, children before parents: out[k]
+// becomes device node node_base + k.  Returns the root reference (the last node) and the height of the whole tree.
+void build_sah_over_clusters(int m, const float *cmin4, const float *cmax4, const int32_t *cref, const int32_t *clevels, int node_base,
+                             std::vector<Node> &out, int32_t &root_ref, int32_t &height) {
+    std::vector<BObj> objs((size_t)m);
+    std::vector<BObj *> ptrs((size_t)m);
+    for (int i = 0; i < m; ++i) {
+        objs[(size_t)i].prim = i;
+        objs[(size_t)i].bounds.mn = {cmin4[4 * i], cmin4[4 * i + 1], cmin4[4 * i + 2]};
+        objs[(size_t)i].bounds.mx = {cmax4[4 * i], cmax4[4 * i + 1], cmax4[4 * i + 2]};
+        objs[(size_t)i].area = 0.f;
+        objs[(size_t)i].mesh_root = nullptr;
+        ptrs[(size_t)i] = &objs[(size_t)i];
+    }
+    Arena arena;
+    init_builders();
+    const BNode *root = sah_build(arena, ptrs, 0, ptrs.size());
+    struct Emit {
+        const int32_t *cref, *clevels;
+        int node_base;
+        std::vector<Node> &out;
+        // -> {child reference, levels below and including this node}
+        std::pair<int32_t, int32_t> run(const BNode *n) {
+            if (n->obj) return {cref[n->obj->prim], clevels[n->obj->prim]};
+            const auto l = run(n->left), r = run(n->right);
+            Node N;
+            std::memset(&N, 0, sizeof N);
+            store3(N.lmin, n->left->bounds.mn);
+            store3(N.lmax, n->left->bounds.mx);
+            store3(N.rmin, n->right->bounds.mn);
+            store3(N.rmax, n->right->bounds.mx);
+            N.left = l.first;
+            N.right = r.first;
+            out.push_back(N);
+            return {node_base + (int32_t)out.size() - 1, 1 + std::max(l.second, r.second)};
+        }
+    } E{cref, clevels, node_base, out};
+    const auto r = E.run(root);
+    root_ref = r.first;
+    height = r.second;
+}
+
+
 BuildChoice resolve_build_choice(const mcpt_build_options *opt) {
     BuildChoice c;
     int builder = opt ? opt->builder : MCPT_BUILD_DEFAULT;
@@ -453,6 +541,7 @@ BuildChoice resolve_build_choice(const mcpt_build_options *opt) {
         const char *e = std::getenv("MCPT_BVH");
         if (e && std::strcmp(e, "reference") == 0) builder = MCPT_BUILD_REFERENCE;
         else if (e && std::strcmp(e, "lbvh") == 0) builder = MCPT_BUILD_GPU_LBVH;
+        else if (e && std::strcmp(e, "ploc") == 0) builder = MCPT_BUILD_GPU_PLOC;
         else builder = MCPT_BUILD_SAH;
     }
     if (quant < 0) {
@@ -467,6 +556,8 @@ BuildChoice resolve_build_choice(const mcpt_build_options *opt) {
         else if (e && e[0] == '1') inst = 1;
     }
     c.builder = builder;
+    if (const char *r = std::getenv("MCPT_PLOC_RADIUS")) c.ploc_radius = std::max(1, std::atoi(r));
+    if (const char *r = std::getenv("MCPT_PLOC_TOP")) c.ploc_top = std::max(0, std::atoi(r));
     c.quantise = quant;
     c.instancing = inst;
     return c;
@@ -474,11 +565,12 @@ BuildChoice resolve_build_choice(const mcpt_build_options *opt) {
 
 int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, const BuildChoice &choice) {
     *err = "";
-    if (choice.builder != MCPT_BUILD_SAH && choice.builder != MCPT_BUILD_REFERENCE && choice.builder != MCPT_BUILD_GPU_LBVH) {
+    if (choice.builder != MCPT_BUILD_SAH && choice.builder != MCPT_BUILD_REFERENCE && choice.builder != MCPT_BUILD_GPU_LBVH &&
+        choice.builder != MCPT_BUILD_GPU_PLOC) {
         *err = "unknown builder in mcpt_build_options";
         return MCPT_ERR_ARG;
     }
-    const bool gpu_build = choice.builder == MCPT_BUILD_GPU_LBVH;
+    const bool gpu_build = choice.builder == MCPT_BUILD_GPU_LBVH || choice.builder == MCPT_BUILD_GPU_PLOC;
     const bool mesh_trees = choice.builder == MCPT_BUILD_REFERENCE;  // otherwise only emissive meshes need their own tree
     if (d.n_objects <= 0 || !d.objects || d.n_materials <= 0 || !d.materials || d.n_triangles < 0 ||
         (d.n_triangles > 0 && !d.triangles)) {
@@ -487,6 +579,13 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, 
     }
     hs.n_triangles = d.n_triangles;
     hs.n_objects = d.n_objects;
+    const bool verbose = std::getenv("MCPT_BVH_VERBOSE") != nullptr;
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char *what) {  // MCPT_BVH_VERBOSE: where the host side of mcpt_scene_create spends its time
+        const auto now = std::chrono::steady_clock::now();
+        if (verbose) std::fprintf(stderr, "[mcpt build] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_phase).count());
+        t_phase = now;
+    };
 
     // materials, Material.hpp:245-262
     hs.materials.resize(d.n_materials);
@@ -617,10 +716,11 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, 
         }
     }
 
+    phase("records, boxes, light trees");
     Flattener F{hs};
     if (gpu_build) {
         // the traversal tree is built on the device by the caller (csrc/mcpt_lbvh.hip); keep the device array non-empty
-        hs.builder = 2;
+        hs.builder = choice.builder == MCPT_BUILD_GPU_PLOC ? 3 : 2;
         hs.root = 0;
         hs.height = 0;
         hs.nodes.clear();
@@ -716,6 +816,7 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, 
             }
             std::vector<BObj *> ptrs;
             for (BObj &o : objs) ptrs.push_back(&o);
+            init_builders();
             const BNode *proot = sah_build(arena, ptrs, 0, ptrs.size());
             Flattener PF{hs};
             const int32_t root_ref = PF.flatten(proot, 1);  // (n_tri >= 64: an inner node)
@@ -760,7 +861,10 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, 
             else
                 for (int k = 0; k < d.objects[oi].n_tri; ++k) prims.push_back(&tri_objs[d.objects[oi].first_tri + k]);
         }
+        init_builders();
+        phase("instancing, primitive list");
         BNode *r = sah_build(arena, prims, 0, prims.size());
+        phase("binned SAH build");
         const char *e = std::getenv("MCPT_BVH_REINSERT");
         const int passes = e ? std::atoi(e) : kReinsertPasses;
         if (inst_leaf_objs.empty()) r = reinsertion_optimise(arena, r, passes, std::getenv("MCPT_BVH_VERBOSE") != nullptr);
@@ -771,6 +875,7 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, 
     F.first_instance_leaf = hs.n_leaf_prims;
     F.extra = &inst_extra;
     hs.root = F.flatten(root, 1);
+    phase("flatten");
     hs.height = F.height;
     store3(hs.root_min, root->bounds.mn);
     store3(hs.root_max, root->bounds.mx);
@@ -896,6 +1001,7 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, 
         hs.env_h = d.env_h;
         hs.env.assign(d.env_pixels, d.env_pixels + (size_t)d.env_w * d.env_h * 3);
     }
+    phase("quantised nodes, light tables");
     return MCPT_OK;
 }
 

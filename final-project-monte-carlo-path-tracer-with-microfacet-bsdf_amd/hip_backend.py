@@ -57,7 +57,7 @@ class BuildOptions(C.Structure):
     _fields_ = [("builder", C.c_int32), ("quantise", C.c_int32), ("instancing", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
-BUILDERS = {"default": 0, "sah": 1, "reference": 2, "lbvh": 3}  # MCPT_BUILD_*
+BUILDERS = {"default": 0, "sah": 1, "reference": 2, "lbvh": 3, "ploc": 4}  # MCPT_BUILD_*
 
 
 class SceneInfo(C.Structure):
@@ -192,7 +192,7 @@ class HipScene:
 
     def __init__(self, sd, device=-1, library=None, builder=None, quantise=-1, instancing=None):
         """library: path of an alternative build of the same ABI (the checking build); None = the product library.
-        builder: None (mcpt_scene_create: environment / default) or "sah" | "reference" | "lbvh" (mcpt_scene_create_ex)."""
+        builder: None (mcpt_scene_create: environment / default) or "sah" | "reference" | "lbvh" | "ploc" (mcpt_scene_create_ex)."""
         self.sd = sd
         self._keep = []
         self.L = lib(library)

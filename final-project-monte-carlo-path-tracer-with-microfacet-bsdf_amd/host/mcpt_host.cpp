@@ -254,6 +254,9 @@ struct CheckpointHeader {
     int32_t n_dir;
     float rr_rate;
     uint32_t scene_hash;
+    int32_t enable_shadow, max_depth;  // (MCPTCKP2: a resume after includeShadow, the depth limit or the environment map changed would
+    uint32_t env_hash;                 //  sum samples of two different integrands into one frame)
+    uint32_t reserved;
 };
 
 uint32_t fnv1a(const void *data, size_t n, uint32_t h) {
@@ -283,7 +286,8 @@ bool load_checkpoint(const std::string &file, const CheckpointHeader &want, std:
     CheckpointHeader h{};
     in.read((char *)&h, sizeof h);
     if (!in || std::memcmp(h.magic, want.magic, 8) != 0 || h.width != want.width || h.height != want.height || h.spp_total != want.spp_total ||
-        h.seed != want.seed || h.n_dir != want.n_dir || h.rr_rate != want.rr_rate || h.scene_hash != want.scene_hash || h.spp_done <= 0 ||
+        h.seed != want.seed || h.n_dir != want.n_dir || h.rr_rate != want.rr_rate || h.scene_hash != want.scene_hash || h.enable_shadow != want.enable_shadow ||
+        h.max_depth != want.max_depth || h.env_hash != want.env_hash || h.spp_done <= 0 ||
         h.spp_done > h.spp_total)
         return false;
     std::vector<float> tmp(fb.size());
@@ -333,7 +337,7 @@ void Renderer::Render(const Scene &scene) {
         if (rc != MCPT_OK && rc != MCPT_ERR_OVERFLOW) return;
     } else {
         CheckpointHeader h{};
-        std::memcpy(h.magic, "MCPTCKP1", 8);
+        std::memcpy(h.magic, "MCPTCKP2", 8);
         h.width = camera.width;
         h.height = camera.height;
         h.spp_total = spp;
@@ -341,6 +345,13 @@ void Renderer::Render(const Scene &scene) {
         h.n_dir = p.n_dir_sample;
         h.rr_rate = p.rr_rate;
         h.scene_hash = scene_hash(scene);
+        h.enable_shadow = p.enable_shadow;
+        h.max_depth = p.max_depth;
+        h.env_hash = 0u;
+        if (scene.useEnvMap) {
+            const unsigned dims[2] = {scene.envWidth, scene.envHeight};
+            h.env_hash = fnv1a(scene.envPixels.data(), scene.envPixels.size() * sizeof(float), fnv1a(dims, sizeof dims, 2166136261u));
+        }
         int done = 0;
         if (load_checkpoint(checkpoint_path, h, framebuffer, done))
             std::cout << "[mcpt] resuming from " << checkpoint_path << " at " << done << " of " << spp << " spp" << std::endl;

@@ -120,7 +120,9 @@ struct Huff {
         throw 2;
     }
 };
-inline bool inflate(const std::vector<uint8_t> &z, std::vector<uint8_t> &out) {
+// `limit`: the decoded size the caller expects (the filtered scanlines of the IHDR's image).  The output never grows beyond it: a small
+// crafted IDAT cannot expand into gigabytes before the unfilter step rejects it.
+inline bool inflate(const std::vector<uint8_t> &z, std::vector<uint8_t> &out, size_t limit) {
     static const uint16_t lbase[] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint16_t lext[] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
     static const uint16_t dbase[] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
@@ -137,7 +139,7 @@ inline bool inflate(const std::vector<uint8_t> &z, std::vector<uint8_t> &out) {
                 if (br.pos + 4 > br.n) return false;
                 const unsigned len = br.d[br.pos] | (br.d[br.pos + 1] << 8);
                 br.pos += 4;
-                if (br.pos + len > br.n) return false;
+                if (br.pos + len > br.n || out.size() + len > limit) return false;
                 out.insert(out.end(), br.d + br.pos, br.d + br.pos + len);
                 br.pos += len;
             } else if (type == 1 || type == 2) {
@@ -176,15 +178,17 @@ inline bool inflate(const std::vector<uint8_t> &z, std::vector<uint8_t> &out) {
                 }
                 while (true) {
                     const int sym = lit.decode(br);
-                    if (sym < 256) out.push_back((uint8_t)sym);
-                    else if (sym == 256) break;
+                    if (sym < 256) {
+                        if (out.size() >= limit) return false;
+                        out.push_back((uint8_t)sym);
+                    } else if (sym == 256) break;
                     else {
                         if (sym - 257 >= 29) return false;
                         const int len = lbase[sym - 257] + br.bits(lext[sym - 257]);
                         const int ds = dist.decode(br);
                         if (ds >= 30) return false;
                         const size_t d = dbase[ds] + br.bits(dext[ds]);
-                        if (d > out.size()) return false;
+                        if (d > out.size() || out.size() + (size_t)len > limit) return false;
                         for (int k = 0; k < len; ++k) out.push_back(out[out.size() - d]);
                     }
                 }
@@ -271,8 +275,19 @@ inline std::string decode_rgba(const std::string &path, std::vector<uint8_t> &rg
     if (ctype == 3 && plte.size() < 3) return "palette image without PLTE";
     try {
         std::vector<uint8_t> raw;
-        if (!inflate(z, raw)) return "corrupt zlib stream";
         const int bits = c * depth;              // bits per pixel
+        // what the zlib stream may decode to: one filter byte + the packed row, per row (per Adam7 pass when interlaced)
+        size_t expect = 0;
+        if (!interlace) {
+            expect = (size_t)h * (((size_t)w * bits + 7) / 8 + 1);
+        } else {
+            static const unsigned ax0[7] = {0, 4, 0, 2, 0, 1, 0}, ay0[7] = {0, 0, 4, 0, 2, 0, 1}, adx[7] = {8, 8, 4, 4, 2, 2, 1}, ady[7] = {8, 8, 8, 4, 4, 2, 2};
+            for (int p = 0; p < 7; ++p) {
+                const size_t pw = w > ax0[p] ? (w - ax0[p] + adx[p] - 1) / adx[p] : 0, ph = h > ay0[p] ? (h - ay0[p] + ady[p] - 1) / ady[p] : 0;
+                if (pw && ph) expect += ph * ((pw * bits + 7) / 8 + 1);
+            }
+        }
+        if (!inflate(z, raw, expect)) return "corrupt zlib stream";
         const int bpp = std::max(1, bits / 8);   // filter distance
         rgba.assign((size_t)w * h * 4, 255);
         // writes pixel (x, y) from sample position `i` of an unfiltered row

@@ -132,10 +132,12 @@ void mcpt_scene_destroy(mcpt_scene *scene);
  *   MCPT_BUILD_SAH        host, binned SAH over all primitives (default)
  *   MCPT_BUILD_REFERENCE  host, the reference's two-level median-split topology (BVH.cpp:27-93), flattened
  *   MCPT_BUILD_GPU_LBVH   on the device: Morton-code linear BVH (radix sort + Karras hierarchy + bottom-up refit); milliseconds
+ *   MCPT_BUILD_GPU_PLOC   on the device: parallel locally-ordered clustering over the same Morton order (merges chosen by surface area:
+ *                         a tree of near-SAH quality in a few milliseconds; search radius MCPT_PLOC_RADIUS, default 16)
  *                         instead of seconds for large scenes, at a lower tree quality
- * Fields left at MCPT_BUILD_DEFAULT / -1 take the environment overrides MCPT_BVH = sah | reference | lbvh and
+ * Fields left at MCPT_BUILD_DEFAULT / -1 take the environment overrides MCPT_BVH = sah | reference | lbvh | ploc and
  * MCPT_QUANT_NODES = 0 | 1, then the defaults. */
-enum { MCPT_BUILD_DEFAULT = 0, MCPT_BUILD_SAH = 1, MCPT_BUILD_REFERENCE = 2, MCPT_BUILD_GPU_LBVH = 3 };
+enum { MCPT_BUILD_DEFAULT = 0, MCPT_BUILD_SAH = 1, MCPT_BUILD_REFERENCE = 2, MCPT_BUILD_GPU_LBVH = 3, MCPT_BUILD_GPU_PLOC = 4 };
 typedef struct {
     int32_t builder;  /* MCPT_BUILD_* */
     int32_t quantise; /* -1 automatic, 0 float nodes (64 B), 1 quantised nodes (32 B) */
@@ -213,7 +215,7 @@ typedef struct {
     uint64_t scene_bytes;
     double build_ms;  /* flattening + BVH build (the data producer of BVHAccel::recursiveBuild, BVH.cpp:27-93) */
     double upload_ms; /* host -> HBM copies */
-    int32_t builder;  /* 0 host binned SAH, 1 host reference topology (median split), 2 GPU LBVH */
+    int32_t builder;  /* 0 host binned SAH, 1 host reference topology (median split), 2 GPU LBVH, 3 GPU PLOC */
     int32_t quantised;/* 1: 32-byte nodes with 16-bit boxes are traversed */
     int32_t n_instances; /* objects whose traversal nodes are shared with a prototype (0: plain tree) */
     int32_t lds_resident; /* 1: the scene is small enough for the kernels that copy nodes, triangles, spheres and light tables into LDS */

@@ -42,8 +42,8 @@ def hip_check(pkg, hip):
     return path
 
 
-# MCPT_BVH x MCPT_QUANT_NODES (None = automatic); lbvh = the tree built on the GPU
-TREES = [("sah", None), ("sah", "0"), ("reference", "0"), ("reference", "1"), ("lbvh", None), ("lbvh", "0")]
+# MCPT_BVH x MCPT_QUANT_NODES (None = automatic); lbvh / ploc = the trees built on the GPU
+TREES = [("sah", None), ("sah", "0"), ("reference", "0"), ("reference", "1"), ("lbvh", None), ("lbvh", "0"), ("ploc", None)]
 
 
 @pytest.fixture

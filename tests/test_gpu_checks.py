@@ -92,3 +92,65 @@ def test_retry_flavour_of_the_traversal_stack(pkg, hip, hip_check, builder):
         assert np.array_equal(fa, fb, equal_nan=True) and sa.vertices == sb.vertices and sa.shadow_rays == sb.shadow_rays
         prod.close()
         chk.close()
+
+
+def _random_dirac_scene(pkg, rng):
+    """Random emitters (1-3 quads and, sometimes, an emissive sphere) with random mirrors, glass spheres and glass slabs scattered around
+    and close to them, over a rough floor: the configurations direct_is_zero's cone rule has to classify."""
+    s = pkg.scenes
+    P = s.material_presets()
+    b = s._Builder()
+    for k in range(int(rng.integers(1, 4))):
+        c = rng.uniform([-3, 1.5, -3], [3, 4, 3])
+        e = rng.uniform(0.2, 1.2)
+        u, v = rng.normal(size=3), rng.normal(size=3)
+        u /= np.linalg.norm(u)
+        v -= u * (u @ v)
+        v /= np.linalg.norm(v)
+        light = s._mat(s.ROUGH_CONDUCTOR, emission=tuple(rng.uniform(10, 60, 3)))
+        b.add_mesh(_quad(pkg, c - e * u - e * v, c + e * u - e * v, c + e * u + e * v, c - e * u + e * v), b.material("light%d" % k, light))
+    b.add_mesh(_quad(pkg, (-8, 0, -8), (-8, 0, 8), (8, 0, 8), (8, 0, -8)), b.material("rough_white_conductor", P["rough_white_conductor"]))
+    for k in range(int(rng.integers(3, 9))):
+        c = rng.uniform([-4, 0.2, -4], [4, 4.5, 4])
+        kind = int(rng.integers(0, 3))
+        if kind == 0:  # a mirror quad with a random orientation
+            e = rng.uniform(0.3, 1.5)
+            u, v = rng.normal(size=3), rng.normal(size=3)
+            u /= np.linalg.norm(u)
+            v -= u * (u @ v)
+            v /= np.linalg.norm(v)
+            name = str(rng.choice(["silver_mirror", "gold_conductor"]))
+            b.add_mesh(_quad(pkg, c - e * u - e * v, c + e * u - e * v, c + e * u + e * v, c - e * u + e * v), b.material(name, P[name]))
+        elif kind == 1:
+            name = str(rng.choice(["smooth_glass", "smooth_glass_gem", "silver_mirror"]))
+            b.add_sphere(tuple(c), float(rng.uniform(0.15, 0.9)), b.material(name, P[name]))
+        else:  # a thin glass slab: two faces, refraction from inside
+            e, th = rng.uniform(0.4, 1.2), rng.uniform(0.05, 0.4)
+            top, bot = c[1] + th, c[1]
+            b.add_mesh(np.concatenate([_quad(pkg, (c[0] - e, top, c[2] - e), (c[0] - e, top, c[2] + e), (c[0] + e, top, c[2] + e), (c[0] + e, top, c[2] - e)),
+                                       _quad(pkg, (c[0] - e, bot, c[2] - e), (c[0] + e, bot, c[2] - e), (c[0] + e, bot, c[2] + e), (c[0] - e, bot, c[2] + e))]),
+                       b.material("smooth_glass", P["smooth_glass"]))
+    cam = s.make_camera(80, 56, 60, tuple(rng.uniform([-2, 1, -7], [2, 3, -5])), (0.0, 1.5, 0.0))
+    return s.SceneData(triangles=np.concatenate(b.tris).astype(s.TRI_DTYPE), materials=np.stack(b.mats).astype(s.MAT_DTYPE),
+                       objects=np.stack(b.objs).astype(s.OBJ_DTYPE), background=np.float32([0.02, 0.02, 0.03]), camera=cam,
+                       rr_rate=float(rng.choice([0.5, 0.8])), spp=8, name="random dirac scene")
+
+
+def test_skipped_direct_lighting_is_zero_on_random_scenes(pkg, hip, hip_check):
+    """direct_is_zero on geometry nobody designed: 24 random scenes of mirrors and glass around random emitters, rendered by the checking
+    build (which evaluates every skipped vertex anyway): not one non-zero contribution among the skipped light samples; and the product
+    build renders the same frames."""
+    rng = np.random.default_rng(2024)
+    tot_skipped = 0
+    for k in range(24):
+        sd = _random_dirac_scene(pkg, rng)
+        hc = hip.HipScene(sd, library=hip_check)
+        fb_check, _ = hc.render(spp=8, seed=k)
+        c = hc.debug_counters()
+        assert int(c[15]) == 0, (k, int(c[14]), int(c[15]))
+        tot_skipped += int(c[14])
+        fb, _ = hip.HipScene(sd).render(spp=8, seed=k)
+        assert np.array_equal(fb, fb_check, equal_nan=True), k
+        hc.close()
+    print("\n[direct-skip check] 24 random scenes: %d light samples at skipped vertices, 0 non-zero" % tot_skipped)
+    assert tot_skipped > 100000

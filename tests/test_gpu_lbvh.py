@@ -1,4 +1,5 @@
-"""The GPU BVH builder (csrc/mcpt_lbvh.hip, MCPT_BUILD_GPU_LBVH): the tree it leaves in HBM satisfies the invariants of the host
+"""The GPU BVH builders (csrc/mcpt_lbvh.hip: MCPT_BUILD_GPU_LBVH, the linear BVH, and MCPT_BUILD_GPU_PLOC, parallel locally-ordered
+clustering, the one of near-SAH quality): the tree they leave in HBM satisfies the invariants of the host
 builders' trees (tests/test_bvh_host.py: every primitive in exactly one leaf, child boxes contain what is below them, the
 declared stack bound covers the height, quantised boxes contain the exact ones), closest hits are bit-identical to the oracle's
 full traversal, and frames equal those rendered with the host-built SAH tree."""
@@ -26,21 +27,38 @@ def _soup(pkg, n=3000, seed=5, duplicates=True):
                                 env_pixels=None, camera=base.camera, rr_rate=base.rr_rate)
 
 
+def sah_cost(boxes, root_min, root_max):
+    """Sum of the surface areas of all inner nodes' boxes (every child box that is not a leaf's, plus the root) over the root's: the
+    expected number of node visits of a random ray through the root box -- what the SAH minimises."""
+    def area(mn, mx):
+        d = np.maximum(mx - mn, 0).astype(np.float64)
+        return d[..., 0] * d[..., 1] + d[..., 1] * d[..., 2] + d[..., 2] * d[..., 0]
+    b = boxes.reshape(-1, 2, 2, 3).astype(np.float64)  # node, child, (min, max), xyz
+    node_mn, node_mx = b[:, :, 0].min(axis=1), b[:, :, 1].max(axis=1)
+    return float(area(node_mn, node_mx).sum() / area(np.asarray(root_min, np.float64), np.asarray(root_max, np.float64)))
+
+
+@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
 @pytest.mark.parametrize("name", ["cornell_demo", "chess", "soup", "chess_high"])
-def test_gpu_built_tree_invariants_and_hits(pkg, oracle, hip, name, capsys):
+def test_gpu_built_tree_invariants_and_hits(pkg, oracle, hip, name, builder, capsys):
     sd = {"cornell_demo": lambda: pkg.scenes.cornell_demo(64, 64, 2), "chess": lambda: pkg.scenes.chess_scene(width=160, height=90, spp=2),
           "soup": lambda: _soup(pkg), "chess_high": lambda: pkg.scenes.chess_high(160, 90, 2)}[name]()
-    hs = hip.HipScene(sd, builder="lbvh")
+    hs = hip.HipScene(sd, builder=builder)
     info, boxes, children, qboxes = hs.dump_bvh()
     n_prims = len(sd.triangles) + int((sd.objects["kind"] == 1).sum())
     assert info["n_nodes"] == n_prims - 1 == len(boxes)
     h = check_tree(sd, info, boxes, children, qboxes)
     meta = hs.info()
-    assert meta["builder"] == 2 and meta["bvh_height"] == info["stack_entries"] and h + 1 == info["stack_entries"]
-    sah = hip.HipScene(sd, builder="sah").info()
+    assert meta["builder"] == (2 if builder == "lbvh" else 3) and meta["bvh_height"] == info["stack_entries"] and h + 1 == info["stack_entries"]
+    hsah = hip.HipScene(sd, builder="sah")
+    sah = hsah.info()
+    si, sboxes, _, _ = hsah.dump_bvh()
+    cost, cost_sah = sah_cost(boxes, info["root_min"], info["root_max"]), sah_cost(sboxes, si["root_min"], si["root_max"])
     with capsys.disabled():
-        print("\n[lbvh] %-12s %7d prims: GPU build %.2f ms (height %d, quantised %d)  |  host SAH build %.1f ms (height %d)"
-              % (name, n_prims, meta["build_ms"], meta["bvh_height"], meta["quantised"], sah["build_ms"], sah["bvh_height"]))
+        print("\n[%s] %-12s %7d prims: GPU build %.2f ms (height %d, quantised %d, SAH cost %.2f)  |  host SAH build %.1f ms (height %d, SAH cost %.2f)"
+              % (builder, name, n_prims, meta["build_ms"], meta["bvh_height"], meta["quantised"], cost, sah["build_ms"], sah["bvh_height"], cost_sah))
+    if builder == "ploc" and name in ("chess", "chess_high"):
+        assert cost < 1.25 * cost_sah  # (the linear BVH: 1.5-2x)
     # closest hits against the oracle's full traversal of the reference's tree: bit-exact
     rng = np.random.default_rng(3)
     n = 20000
@@ -60,7 +78,7 @@ def test_gpu_built_tree_invariants_and_hits(pkg, oracle, hip, name, capsys):
 def test_frames_do_not_depend_on_the_builder(pkg, hip, name):
     sd = pkg.scenes.cornell_demo(96, 96, 8) if name == "cornell_demo" else pkg.scenes.chess_scene(width=240, height=135, spp=8)
     ref, st0 = hip.HipScene(sd, builder="sah").render(spp=8, seed=6)
-    for builder, quant in (("lbvh", -1), ("lbvh", 0), ("reference", -1)):
+    for builder, quant in (("lbvh", -1), ("lbvh", 0), ("ploc", -1), ("ploc", 0), ("reference", -1)):
         fb, st = hip.HipScene(sd, builder=builder, quantise=quant).render(spp=8, seed=6)
         differing = int((~((fb == ref) | (np.isnan(fb) & np.isnan(ref)))).sum())
         assert differing <= 3, (builder, quant, differing)  # (a box-grazing ray may take another branch)
@@ -111,6 +129,8 @@ def test_deep_trees_are_exact_and_too_deep_ones_are_refused(pkg, oracle, hip):
     heights = []
     for n in (24, 36, 45, 63):
         sd = _chain(pkg, n)
+        hp = hip.HipScene(sd, builder="ploc")  # (merges by surface area: no chain, whatever the codes look like)
+        assert hp.info()["bvh_height"] <= 48
         try:
             hs = hip.HipScene(sd, builder="lbvh")
         except RuntimeError as e:
@@ -128,6 +148,6 @@ def test_deep_trees_are_exact_and_too_deep_ones_are_refused(pkg, oracle, hip):
         t_gpu, p_gpu = hs.intersect(o, d)
         assert np.array_equal(p_ref, p_gpu) and np.array_equal(t_ref[p_ref >= 0], t_gpu[p_ref >= 0])
         t_sah, p_sah = hip.HipScene(sd, builder="sah").intersect(o, d)
-        assert np.array_equal(p_sah, p_gpu)
+        assert np.array_equal(p_sah, p_gpu) and np.array_equal(hp.intersect(o, d)[1], p_gpu)
     print("\n[lbvh] chain scenes: heights", heights)
     assert any(h is not None and h > 24 for h in heights), heights  # the retry flavour was in use

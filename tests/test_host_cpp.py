@@ -153,7 +153,7 @@ def test_checkpoint_and_resume(pkg, hip, host_bins, tmp_path):
     ck = str(tmp_path / "frame.ckpt")
     o1 = run(["--checkpoint", ck, "--checkpoint-every", "3", "--stop-after", "6"], "never_written.png")
     assert "stopped after 6 spp" in o1 and os.path.exists(ck) and not os.path.exists(tmp_path / "never_written.png")
-    assert os.path.getsize(ck) == 40 + 80 * 60 * 3 * 4
+    assert os.path.getsize(ck) == 56 + 80 * 60 * 3 * 4  # (MCPTCKP2 header)
     o2 = run(["--checkpoint", ck, "--checkpoint-every", "3"], "resumed.png")
     assert "resuming from" in o2 and "at 6 of 10 spp" in o2
     assert open(tmp_path / "plain.png", "rb").read() == open(tmp_path / "resumed.png", "rb").read()
@@ -167,6 +167,25 @@ def test_checkpoint_and_resume(pkg, hip, host_bins, tmp_path):
     assert p.returncode == 0 and "resuming" not in p.stdout
     fb, _ = hip.HipScene(pkg.scenes.cornell_demo(40, 30, 4)).render(spp=4, seed=1)
     assert np.array_equal(pkg.pngio.read_png(str(tmp_path / "small.png"))[:, :, :3], pkg.pngio.tonemap_u8(fb))
+    # the same scene with another integrand (includeShadow switched off between the two runs): the checkpoint must not be resumed,
+    # or samples with and without shadows would be summed into one frame
+    conf = json.loads(json.dumps(pkg.scenes.DEFAULT_CONF))
+    conf["camera"]["width"], conf["camera"]["height"], conf["renderer"]["spp"] = 96, 54, 4
+    (tmp_path / "conf.json").write_text(json.dumps(conf))
+    ck2 = str(tmp_path / "chess.ckpt")
+    chess = [host_bins[0], "--models", MODELS, "--checkpoint", ck2, "--checkpoint-every", "2"]
+    p = subprocess.run(chess + ["--stop-after", "2", "--output", str(tmp_path / "c0.png")], cwd=str(tmp_path), capture_output=True, text=True)
+    assert p.returncode == 0 and "stopped after 2 spp" in p.stdout, p.stderr
+    conf["scene"]["includeShadow"] = False
+    (tmp_path / "conf.json").write_text(json.dumps(conf))
+    p = subprocess.run(chess + ["--output", str(tmp_path / "c1.png")], cwd=str(tmp_path), capture_output=True, text=True)
+    assert p.returncode == 0 and "resuming" not in p.stdout, p.stdout
+    conf["scene"]["includeShadow"] = True
+    (tmp_path / "conf.json").write_text(json.dumps(conf))
+    os.remove(ck2)
+    p = subprocess.run(chess + ["--stop-after", "2", "--output", str(tmp_path / "c0.png")], cwd=str(tmp_path), capture_output=True, text=True)
+    p = subprocess.run(chess + ["--output", str(tmp_path / "c2.png")], cwd=str(tmp_path), capture_output=True, text=True)
+    assert p.returncode == 0 and "resuming from" in p.stdout  # (unchanged configuration: resumed)
 
 
 def test_host_parsers_under_asan(pkg, hip, tmp_path):

@@ -170,3 +170,25 @@ def test_decoder_rejects_broken_files(png_tool, tmp_path):
         open(path, "wb").write(blob)
         got, err = _decode(png_tool, path, tmp_path)
         assert got is None and err, name
+
+
+def test_decoder_bounds_the_inflated_size(png_tool, tmp_path):
+    """A 4x4 image whose IDAT decompresses to 64 MiB (a zlib bomb: 64 KB of file): the decoder knows from the IHDR that 52 bytes are due
+    and must stop there -- an error, quickly, without ever holding the 64 MiB."""
+    import time
+    sig = b"\x89PNG\r\n\x1a\n"
+    ihdr = struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 0)
+    bomb = zlib.compress(bytes(64 << 20), 9)
+    assert len(bomb) < 100_000
+    path = str(tmp_path / "bomb.png")
+    open(path, "wb").write(sig + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", bomb) + _chunk(b"IEND", b""))
+    t0 = time.time()
+    p = subprocess.run([png_tool, path, str(tmp_path / "o.rgba")], capture_output=True, text=True)
+    assert p.returncode == 1 and "corrupt zlib stream" in (p.stdout + p.stderr), (p.returncode, p.stderr[-500:])
+    assert time.time() - t0 < 5.0
+    # one byte too many is an error as well; exactly the expected size decodes
+    rows = b"".join(b"\x00" + bytes(12) for _ in range(4))
+    for extra, ok in ((b"", True), (b"\x00", False)):
+        open(path, "wb").write(sig + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", zlib.compress(rows + extra)) + _chunk(b"IEND", b""))
+        got, err = _decode(png_tool, path, tmp_path)
+        assert (got is not None) == ok, (extra, err)
