@@ -238,7 +238,10 @@ constexpr int kStkRetry = MCPT_STK_RETRY;  // LDS entries of the retry flavour (
 // (first_tri + local index), so hits are exactly those of the un-instanced tree.  Popping the marker restores the origin.
 constexpr int32_t kNoWork = (int32_t)0x80000000;   // neither an inner node (>= 0) nor a leaf (~index, index < 2^31 - 2)
 constexpr int32_t kInstExit = (int32_t)0x80000001; // stack marker: the subtree of the current instance is exhausted
-constexpr int kLeafVote = 12;
+#ifndef MCPT_LEAF_VOTE
+#define MCPT_LEAF_VOTE 12
+#endif
+constexpr int kLeafVote = MCPT_LEAF_VOTE;
 template <int MODE, int STK, bool SCR, bool MARK, bool FAST, bool QUANT, bool INST>
 MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int32_t *scr, int tid, TraceState &st) {
     QRay qr;
@@ -553,12 +556,13 @@ __global__ __launch_bounds__(kBlock) void k_retrace_closest(DevScene S, const fl
 #define MCPT_RAYS_PER_LANE 4
 #endif
 constexpr uint32_t kRaysPerLane = MCPT_RAYS_PER_LANE, kRefillMin = MCPT_REFILL_MIN;
-// Occupancy: the refill state costs registers (79 VGPRs unconstrained = 6 waves per SIMD).  Bounding the kernel to 7 waves per SIMD
-// (72 VGPRs, 14 spilled) is the measured optimum: frame 4617 (one ray per lane) -> 4645 (unconstrained) -> 4695 (7 waves) ->
-// 4620 (8 waves, 42 spills); refill thresholds 8 / 16 / 32 and 2 / 4 / 8 rays per lane: 4670 / 4695 / 4690 and 4595 / 4695 / 4705.
+// Occupancy: the refill state costs registers.  Round 2: 79 VGPRs unconstrained (6 waves per SIMD); bounded to 7 waves (72 VGPRs, 14 spilled)
+// was the optimum then: frame 4617 (one ray per lane) -> 4645 (unconstrained) -> 4695 (7 waves) -> 4620 (8 waves, 42 spills).  Round 3 moved the
+// generic walk of zero-component rays out of the loop, which freed registers: 69 VGPRs unconstrained, 64 with 4 spills at 8 waves -- frame
+// +0.6..1.1 % over 7 waves (A/B on one box: 4847 -> 4888); 8 rays per lane instead of 4: +0.5 %, refill threshold 8 instead of 16: +0.1 %.
 // (Stacks deeper than 20 entries: LDS bounds the occupancy below 7 anyway, so no register bound there.)
 #ifndef MCPT_REFILL_WAVES
-#define MCPT_REFILL_WAVES 7
+#define MCPT_REFILL_WAVES 8
 #endif
 template <int STK, bool RETRY, bool SMALL>
 __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k_trace_closest_refill(DevScene S, uint32_t n_host, const uint32_t *__restrict__ n_dev,
@@ -965,6 +969,21 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
             }
         }
     }
+#ifdef MCPT_TRAVERSAL_STATS
+    if (S.dbg) {  // how many DIFFERENT primitives the 64 primary rays of a wave hit: what a wave-shared (packet) walk would have to visit at least
+        const int myp = (valid && tr.prim >= 0) ? tr.prim : -2;
+        bool first = myp >= 0;
+        for (int l = 0; l < 64; ++l) {
+            const int op = __shfl(myp, l);
+            if ((uint32_t)l < lane_id() && op == myp) first = false;
+        }
+        const unsigned long long m = __ballot(first), mh = __ballot(myp >= 0);
+        if (lane_id() == 0 && mh) {
+            atomicAdd(&S.dbg[14], (unsigned long long)__popcll(m));
+            atomicAdd(&S.dbg[15], 1ull);
+        }
+    }
+#endif
     primary_finish(S, C, next, next_idx, q, s, valid, pos, dir, tr, sh);
 }
 
