@@ -93,9 +93,9 @@ def host_cores():
 
 
 def load_traffic():
-    """profiles/traffic.json: what the committed rocprofv3 passes of the serialised run measured (tools/make_profile_summary.py):
-    per kernel the HBM bytes per launch (separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied), the
-    serialised average launch duration and the VALU-busy fraction; per job the HBM bytes per sample.  None if absent."""
+    """profiles/traffic.json: what the committed rocprofv3 passes of the serialised runs measured (tools/make_profile_summary.py), one
+    entry per profiled configuration: per kernel the HBM bytes per launch (separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950
+    correction applied), the serialised average launch duration and the VALU-busy fraction; per job the HBM bytes per sample.  None if absent."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as fh:
@@ -267,12 +267,16 @@ def main():
     # Profile-derived fields (limiter, PMC traffic, serialised figures, the dominant kernel of the SERIALISED step) come from
     # profiles/traffic.json and describe one build rendering one configuration: they are used only when this run is that
     # configuration on that build (source tag of csrc/); otherwise the dominant kernel is the live one and those fields are null.
-    prof = load_traffic() or {}
-    pc = prof.get("_config", {})
+    prof_all = load_traffic() or {}
     build_tag = pkg.build.source_tag()
-    prof_ok = bool(prof) and prof.get("_build_tag") == build_tag and \
-        (pc.get("scene"), pc.get("width"), pc.get("height"), pc.get("n_dir")) == (args.scene, W, H, args.n_dir)
-    ser = prof.get("_serialized", {}) if prof_ok else {}
+    prof = {}
+    for entry in prof_all.get("configs", {}).values():
+        c = entry.get("config", {})
+        if (c.get("scene"), c.get("width"), c.get("height"), c.get("n_dir")) == (args.scene, W, H, args.n_dir):
+            prof = entry
+    pc = prof.get("config", {})
+    prof_ok = bool(prof) and prof_all.get("_build_tag") == build_tag
+    ser = prof.get("serialized", {}) if prof_ok else {}
     live_dom = max(kern, key=lambda k: kern[k][0])
     dom = max(ser, key=lambda k: ser[k].get("ms_per_step", 0.0)) if ser and not args.serialized else live_dom
     if dom not in kern:
@@ -286,7 +290,7 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         # PMC bytes per launch were measured on the serialised profile's launches; scale them to this run's launch size (bytes per
         # ray / vertex are what carries over)
-        traffic = prof.get(dom) if prof_ok else None
+        traffic = prof.get("kernels", {}).get(dom) if prof_ok else None
         ser_units = ser.get(dom, {}).get("units_per_launch")
         if traffic and ser_units:
             traffic = int(traffic * (units / n_launch) / ser_units)
@@ -303,14 +307,14 @@ def main():
                     "limiter": None if vb is None else ("valu_issue" if vb > 0.6 else "hbm/latency"),
                     "valu_busy_frac": vb,
                     "serialized": ser.get(dom),
-                    "profile": {"applies": prof_ok, "build_tag": build_tag, "profile_build_tag": prof.get("_build_tag"), "profile_config": pc or None},
+                    "profile": {"applies": prof_ok, "build_tag": build_tag, "profile_build_tag": prof_all.get("_build_tag"), "profile_config": pc or None},
                     "kernel_ms": {k: round(v[0], 2) for k, v in kern.items()},
                     "kernel_launches": {k: int(v[1]) for k, v in kern.items()},
                     "kernel_units": {k: int(v[2]) for k, v in kern.items()}}
     ref_bytes_per_sample = (BYTES_PER_RAY * tot_ref_rays + BYTES_PER_VERTEX * tot_vertices) / tot_samples + BYTES_PER_SAMPLE
     ref_gbs = value * 1e6 * ref_bytes_per_sample / 1e9
     traced_bytes_per_sample = (BYTES_PER_RAY * (tot_closest + tot_shadow) + BYTES_PER_VERTEX * tot_vertices) / tot_samples + BYTES_PER_SAMPLE
-    jt = prof.get("_job", {})
+    jt = prof.get("job", {})
     hbm_bps = jt.get("hbm_bytes_per_sample") if prof_ok else None
 
     # ---- parity vs the CPU oracle, same Philox seed, on a reduced configuration of the same scene
