@@ -1074,6 +1074,7 @@ int upload_scene(const mcpt_scene_desc *desc, HostBuild &hb, int device, mcpt_sc
     v.nodes = sc->nodes.p;
     v.light_area_sum = hs.light_area_sum;
     v.qnodes = sc->qnodes.p;  // nullptr: the float nodes are traversed
+    v.pnodes = nullptr;       // (set by the SMALL kernels to their LDS copy)
     for (int k = 0; k < 3; ++k) {
         v.q_origin[k] = hs.q_origin[k];
         v.q_cell[k] = hs.q_cell[k];

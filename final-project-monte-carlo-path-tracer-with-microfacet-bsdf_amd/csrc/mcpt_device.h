@@ -86,6 +86,7 @@ MCPT_DI void rng_block(const RngKey &k, uint32_t depth, uint32_t block, float u[
 struct DevScene {
     const Node *nodes;
     const QNode *qnodes;  // quantised nodes, or nullptr (then `nodes` is traversed)
+    const float4 *pnodes; // SMALL kernels only: their LDS copy of the quantised nodes as floats relative to q_origin (4 float4 per node), or nullptr
     float q_origin[3], q_cell[3];
     const TriGeom *tri_geom;
     const TriShade *tri_shade;
@@ -181,6 +182,23 @@ MCPT_DI bool qbox_hit(const DevScene &S, const Ray &r, const QRay &qr, uint32_t 
     }
     const float mn[3] = {S.q_origin[0] + (float)mnx * S.q_cell[0], S.q_origin[1] + (float)mny * S.q_cell[1], S.q_origin[2] + (float)mnz * S.q_cell[2]};
     const float mx[3] = {S.q_origin[0] + (float)mxx * S.q_cell[0], S.q_origin[1] + (float)mxy * S.q_cell[1], S.q_origin[2] + (float)mxz * S.q_cell[2]};
+    return box_hit<false>(mn, mx, r, tmin_out, tmax_out);
+}
+
+// Prepared child box (the SMALL kernels' LDS nodes): x' = q * q_cell as a float, so coordinate = q_origin + x' and the slab bound of a ray
+// with finite reciprocals is x' * inv + (q_origin - o) * inv: one FMA, no conversion.  x' carries one rounding (6e-8 of the scene's extent,
+// 0.4 % of a grid cell), the FMA one more: far inside the one-cell margin of the quantised boxes, so the box still contains the exact one.
+template <bool FAST>
+MCPT_DI bool pbox_hit(const DevScene &S, const Ray &r, const QRay &qr, float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                      float &tmin_out, float &tmax_out) {
+    if (FAST) {
+        const float t1x = __builtin_fmaf(mnx, r.inv.x, qr.b.x), t1y = __builtin_fmaf(mny, r.inv.y, qr.b.y), t1z = __builtin_fmaf(mnz, r.inv.z, qr.b.z);
+        const float t2x = __builtin_fmaf(mxx, r.inv.x, qr.b.x), t2y = __builtin_fmaf(mxy, r.inv.y, qr.b.y), t2z = __builtin_fmaf(mxz, r.inv.z, qr.b.z);
+        return box_from_slabs<true>(t1x, t1y, t1z, t2x, t2y, t2z, tmin_out, tmax_out);
+    }
+    // (the same float values the quantised path dequantises to: q_origin + (float)q * q_cell)
+    const float mn[3] = {S.q_origin[0] + mnx, S.q_origin[1] + mny, S.q_origin[2] + mnz};
+    const float mx[3] = {S.q_origin[0] + mxx, S.q_origin[1] + mxy, S.q_origin[2] + mxz};
     return box_hit<false>(mn, mx, r, tmin_out, tmax_out);
 }
 

@@ -130,12 +130,26 @@ MCPT_DI void lds_copy16(void *dst, const void *src, uint32_t n16) {  // n16 16-b
 }
 // (the caller's __syncthreads follows: a kernel that stages both blocks pays for one barrier)
 MCPT_DI void stage_small_geom(DevScene &S, SmallGeomLds &L) {
-    // (both node pointers end up as LDS pointers or null on every path, so that the address-space inference sees no global / LDS mix)
+    // Quantised nodes become "prepared" nodes (traverse_loop, NF = 2): the 16-bit grid coordinates as floats relative to the grid origin,
+    // x' = (float)q * cell, in the layout of Node.  Float nodes are copied as they are.  (Every node pointer the SMALL kernels follow ends up
+    // as an LDS pointer or null on every path, so that the address-space inference sees no global / LDS mix.)
     const bool quant = S.qnodes != nullptr;
-    if (quant) lds_copy16(L.nodes, S.qnodes, (uint32_t)S.n_inner * (uint32_t)(sizeof(QNode) / 16));
-    else lds_copy16(L.nodes, S.nodes, (uint32_t)S.n_inner * (uint32_t)(sizeof(Node) / 16));
+    if (quant) {
+        for (uint32_t i = threadIdx.x; i < (uint32_t)S.n_inner; i += blockDim.x) {
+            const uint4 *q = reinterpret_cast<const uint4 *>(S.qnodes + i);
+            const uint4 a = q[0], b = q[1];
+            const float cx = S.q_cell[0], cy = S.q_cell[1], cz = S.q_cell[2];
+            float4 *o = reinterpret_cast<float4 *>(L.nodes) + 4 * i;
+            o[0] = make_float4((float)(a.x & 0xffffu) * cx, (float)(a.x >> 16) * cy, (float)(a.y & 0xffffu) * cz, (float)(a.y >> 16) * cx);
+            o[1] = make_float4((float)(a.z & 0xffffu) * cy, (float)(a.z >> 16) * cz, (float)(a.w & 0xffffu) * cx, (float)(a.w >> 16) * cy);
+            o[2] = make_float4((float)(b.x & 0xffffu) * cz, (float)(b.x >> 16) * cx, (float)(b.y & 0xffffu) * cy, (float)(b.y >> 16) * cz);
+            o[3] = make_float4(__int_as_float((int32_t)b.z), __int_as_float((int32_t)b.w), 0.f, 0.f);
+        }
+    } else {
+        lds_copy16(L.nodes, S.nodes, (uint32_t)S.n_inner * (uint32_t)(sizeof(Node) / 16));
+    }
     S.nodes = reinterpret_cast<const Node *>(L.nodes);
-    S.qnodes = quant ? reinterpret_cast<const QNode *>(L.nodes) : nullptr;
+    S.pnodes = quant ? reinterpret_cast<const float4 *>(L.nodes) : nullptr;
     lds_copy16(L.tri, S.tri_geom, (uint32_t)S.n_tri * (uint32_t)(sizeof(TriGeom) / 16));
     lds_copy16(L.sph, S.spheres, (uint32_t)S.n_sphere_slots * (uint32_t)(sizeof(SphereRec) / 16));
     S.tri_geom = L.tri;
@@ -242,8 +256,14 @@ constexpr int32_t kInstExit = (int32_t)0x80000001; // stack marker: the subtree 
 #define MCPT_LEAF_VOTE 12
 #endif
 constexpr int kLeafVote = MCPT_LEAF_VOTE;
-template <int MODE, int STK, bool SCR, bool MARK, bool FAST, bool QUANT, bool INST>
+// NF, the node format: 0 float boxes (the exact ones: the reference's own box semantics), 1 quantised (QNode), 2 "prepared" -- the
+// SMALL kernels' LDS copy of the quantised nodes, converted once per workgroup to floats RELATIVE to the grid origin (x' = q * cell), so that
+// a slab bound is ONE fma, x' * inv + (origin - o) * inv, with no integer-to-float conversion per visit (12 of the ~55 vector instructions
+// of a visit).  Same grid, same conservative boxes as format 1 (the error of the form is 0.4 % of the one-cell margin).
+template <int MODE, int STK, bool SCR, bool MARK, bool FAST, int NF, bool INST>
 MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int32_t *scr, int tid, TraceState &st) {
+    constexpr bool QUANT = NF != 0;
+    static_assert(NF != 2 || !INST, "prepared nodes: small scenes, never instanced");
     QRay qr;
     if (QUANT) qr = make_qray(S, r);
     Ray rb = r;               // the ray of the box tests (origin shifted inside an instance)
@@ -291,7 +311,14 @@ MCPT_DI void traverse_loop(const DevScene &S, const Ray &r, float dist, int32_t 
                 float tl = 0.f, tr = 0.f, txl = 0.f, txr = 0.f;
                 bool hl, hr;
                 // every inner node has two children (the builders only emit an inner node for >= 2 primitives)
-                if (QUANT) {  // 32-byte node: two 16-byte requests per lane instead of four
+                if (NF == 2) {  // prepared node (LDS): float boxes relative to the grid origin
+                    const float4 *np = S.pnodes + 4 * cur;
+                    const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+                    left = __float_as_int(e.x);
+                    right = __float_as_int(e.y);
+                    hl = pbox_hit<FAST>(S, rb, qr, a.x, a.y, a.z, a.w, b.x, b.y, tl, txl);
+                    hr = pbox_hit<FAST>(S, rb, qr, b.z, b.w, c.x, c.y, c.z, c.w, tr, txr);
+                } else if (QUANT) {  // 32-byte node: two 16-byte requests per lane instead of four
                     const uint4 *np = reinterpret_cast<const uint4 *>(S.qnodes + cur);
                     const uint4 a = np[0], b = np[1];
                     left = (int32_t)b.z;
@@ -405,12 +432,14 @@ MCPT_DI bool prim_hit(const DevScene &S, int32_t prim, const Ray &r, double &t) 
 // settled (k_direct found the sampled primitive in the window).
 #define MCPT_TL(MODE, FAST, STKN, SCRB, MARKB, SCRP)                                                                  \
     do {                                                                                                              \
-        if (S.inst) {                                                                                                 \
-            if (S.qnodes) traverse_loop<MODE, STKN, SCRB, MARKB, FAST, true, true>(S, r, dist, stk, SCRP, tid, st);   \
-            else traverse_loop<MODE, STKN, SCRB, MARKB, FAST, false, true>(S, r, dist, stk, SCRP, tid, st);           \
+        if (PREP && S.pnodes) { /* SMALL kernels of a scene with quantised nodes */                                   \
+            traverse_loop<MODE, STKN, SCRB, MARKB, FAST, (PREP ? 2 : 1), false>(S, r, dist, stk, SCRP, tid, st);      \
+        } else if (S.inst) {                                                                                          \
+            if (S.qnodes) traverse_loop<MODE, STKN, SCRB, MARKB, FAST, 1, true>(S, r, dist, stk, SCRP, tid, st);      \
+            else traverse_loop<MODE, STKN, SCRB, MARKB, FAST, 0, true>(S, r, dist, stk, SCRP, tid, st);               \
         } else {                                                                                                      \
-            if (S.qnodes) traverse_loop<MODE, STKN, SCRB, MARKB, FAST, true, false>(S, r, dist, stk, SCRP, tid, st);  \
-            else traverse_loop<MODE, STKN, SCRB, MARKB, FAST, false, false>(S, r, dist, stk, SCRP, tid, st);          \
+            if (S.qnodes) traverse_loop<MODE, STKN, SCRB, MARKB, FAST, 1, false>(S, r, dist, stk, SCRP, tid, st);     \
+            else traverse_loop<MODE, STKN, SCRB, MARKB, FAST, 0, false>(S, r, dist, stk, SCRP, tid, st);              \
         }                                                                                                             \
     } while (0)
 #define MCPT_QUERY(STKN, SCRB, MARKB, SCRP)                                        \
@@ -434,6 +463,7 @@ MCPT_DI bool prim_hit(const DevScene &S, int32_t prim, const Ray &r, double &t) 
 // The scratch flavour: the ray again, from the start, with the whole stack in a per-lane array (see MCPT_STK_PUSH).
 template <bool SHADOW>
 MCPT_DI void traverse_again(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, bool found, TraceState &st) {
+    constexpr bool PREP = false;
     int32_t scr[kMaxBvhHeight];
     st.best_t = DBL_MAX;
     st.best_prim = -1;
@@ -444,7 +474,7 @@ MCPT_DI void traverse_again(const DevScene &S, const Ray &r, float dist, int32_t
     MCPT_QUERY(0, true, false, scr);
 }
 
-template <bool SHADOW, int STK, bool RETRY>
+template <bool SHADOW, int STK, bool RETRY, bool PREP = false>
 MCPT_DI TraceResult traverse(const DevScene &S, const Ray &r, float dist, int32_t (*stk)[kBlock], int tid, bool found = false) {
     TraceState st;
     st.best_t = DBL_MAX;
@@ -521,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_closest(DevScene S, uint32_t n
     // grid-stride: when the length is only known on the device the host sizes the grid from an estimate
     for (uint32_t i = blockIdx.x * kBlock + tid; i < n; i += gridDim.x * kBlock) {
         const Ray r = make_ray(ld3(ray_o[i]), ld3(ray_d[i]));
-        const TraceResult tr = traverse<false, STK, RETRY>(S, r, 0.f, stk, tid);
+        const TraceResult tr = traverse<false, STK, RETRY, SMALL>(S, r, 0.f, stk, tid);
         if (RETRY && tr.dropped) retry_append(rl, i);
         else hit[i] = pack_hit(tr.t, tr.prim, tr.mat_bits);
     }
@@ -604,7 +634,7 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
             }
             if (__any(odd)) {
                 if (odd) {
-                    const TraceResult tr = traverse<false, STK, RETRY>(S, ro, 0.f, stk, tid);
+                    const TraceResult tr = traverse<false, STK, RETRY, SMALL>(S, ro, 0.f, stk, tid);
                     if (RETRY && tr.dropped) retry_append(rl, idx);
                     else hit[idx] = pack_hit(tr.t, tr.prim, tr.mat_bits);
                 }
@@ -649,12 +679,24 @@ __global__ __launch_bounds__(kBlock, (STK <= 20 ? MCPT_REFILL_WAVES : 1)) void k
             // ---- phase 1: inner nodes (see traverse_loop)
             while (true) {
                 if (cur >= 0) {
-                    const uint4 *np = reinterpret_cast<const uint4 *>(S.qnodes + cur);
-                    const uint4 a = np[0], b = np[1];
-                    const int32_t left = (int32_t)b.z, right = (int32_t)b.w;
+                    int32_t left, right;
                     float tl = 0.f, tr = 0.f, txl = 0.f, txr = 0.f;
-                    bool hl = qbox_hit<true>(S, r, qr, a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16, a.z & 0xffffu, a.z >> 16, tl, txl);
-                    bool hr = qbox_hit<true>(S, r, qr, a.w & 0xffffu, a.w >> 16, b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16, tr, txr);
+                    bool hl, hr;
+                    if constexpr (SMALL) {  // prepared nodes in LDS (stage_small_geom)
+                        const float4 *np = S.pnodes + 4 * cur;
+                        const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+                        left = __float_as_int(e.x);
+                        right = __float_as_int(e.y);
+                        hl = pbox_hit<true>(S, r, qr, a.x, a.y, a.z, a.w, b.x, b.y, tl, txl);
+                        hr = pbox_hit<true>(S, r, qr, b.z, b.w, c.x, c.y, c.z, c.w, tr, txr);
+                    } else {
+                        const uint4 *np = reinterpret_cast<const uint4 *>(S.qnodes + cur);
+                        const uint4 a = np[0], b = np[1];
+                        left = (int32_t)b.z;
+                        right = (int32_t)b.w;
+                        hl = qbox_hit<true>(S, r, qr, a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16, a.z & 0xffffu, a.z >> 16, tl, txl);
+                        hr = qbox_hit<true>(S, r, qr, a.w & 0xffffu, a.w >> 16, b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16, tr, txr);
+                    }
                     hl = hl && !(tl > lim);
                     hr = hr && !(tr > lim);
                     if (hl && hr) {
@@ -770,7 +812,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(DevScene S, const Count
         const uint32_t e = shadow_entry(pf, pw, i, region, found);
         const float4 o = shq_o[e], d = shq_d[e];
         const Ray r = make_ray(ld3(o), ld3(d));
-        const TraceResult tr = traverse<true, STK, RETRY>(S, r, d.w, stk, tid, found);
+        const TraceResult tr = traverse<true, STK, RETRY, SMALL>(S, r, d.w, stk, tid, found);
         if (RETRY && tr.dropped) retry_append(rl, i);  // (undecided: k_retrace_shadow)
         else if (!tr.visible) contrib[__float_as_uint(o.w)] = 0.f;  // Scene.cpp:74-79: an invisible sample adds nothing
     }
@@ -962,7 +1004,7 @@ __global__ __launch_bounds__(kBlock) void k_primary(DevScene S, CameraConst cam,
     TraceResult tr{DBL_MAX, -1, 0u, false, false};
     if (valid) {
         if (!primary_ray(S, cam, C, q, s, pos, dir, tr)) {
-            tr = traverse<false, STK, RETRY>(S, make_ray(pos, dir), 0.f, stk, tid);
+            tr = traverse<false, STK, RETRY, SMALL>(S, make_ray(pos, dir), 0.f, stk, tid);
             if (RETRY && tr.dropped) {  // the sample is finished by k_primary_retrace
                 retry_append(rl, s);
                 valid = false;
