@@ -16,13 +16,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
-#include <atomic>
 #include <chrono>
-#include <mutex>
-#include <thread>
-#ifdef __linux__
-#include <sched.h>
-#endif
 
 #include "mcpt_internal.h"
 
@@ -76,32 +70,11 @@ struct BNode {  // BVHBuildNode, BVH.hpp:53-69
 
 struct Arena {
     std::vector<std::unique_ptr<BNode>> nodes;
-    std::mutex mu;  // sah_build hands subtrees to helper threads
     BNode *make() {
-        BNode *n = new BNode();
-        std::lock_guard<std::mutex> lock(mu);
-        nodes.emplace_back(n);
-        return n;
+        nodes.emplace_back(new BNode());
+        return nodes.back().get();
     }
 };
-
-// Helper threads of the binned-SAH build: the two halves of a split are independent, so big subtrees are built side by side.  The
-// tree does not depend on how many helpers there are (disjoint ranges, the flattened order comes from the tree, not from the arena).
-// MCPT_BUILD_THREADS (default: the CPUs this process may run on, at most 16; 1 = the sequential build).
-std::atomic<int> g_spare_builders{-1};
-int build_threads() {
-    if (const char *v = std::getenv("MCPT_BUILD_THREADS")) return std::max(1, std::atoi(v));
-    int n = (int)std::thread::hardware_concurrency();
-#ifdef __linux__
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
-#endif
-    return std::min(std::max(n, 1), 16);
-}
-void init_builders() {  // once per process (the helpers are a process-wide budget, shared by scenes built concurrently)
-    int expect = -1;
-    g_spare_builders.compare_exchange_strong(expect, build_threads() - 1);
-}
 
 BNode *recursive_build(Arena &A, std::vector<BObj *> objs) {  // BVH.cpp:27-93
     BNode *node = A.make();
@@ -141,6 +114,28 @@ inline float half_area(const Box &b) {
     return d.x * d.y + d.y * d.z + d.z * d.x;
 }
 
+constexpr int kBins = 32;
+// Bins of one split decision.  Most nodes of a tree are small (half of them have two or three primitives): only the counts are cleared,
+// a bin's box is set by its first primitive, and the cost sweep visits the populated bins only -- the same candidates and the same
+// floats as a sweep over all 32 bins (an empty bin repeats the cost of the populated one before it, and ties keep the first).
+struct SahBins {
+    Box bb[3][kBins];
+    int cnt[3][kBins];
+    void clear() { std::memset(cnt, 0, sizeof cnt); }
+    void add(int a, int b, const Box &box) {
+        bb[a][b] = cnt[a][b] ? box_union(bb[a][b], box) : box;
+        cnt[a][b]++;
+    }
+};
+inline int sah_bin(const BObj *o, int ax, float lo, float scale) {
+    const int b = (int)((axis(centroid(o->bounds), ax) - lo) * scale);
+    return std::min(std::max(b, 0), kBins - 1);
+}
+
+// (Round 3 also built big ranges with helper threads -- chunk-wise binning and partition at the top of the tree, the two halves of a split
+// side by side below: the same tree, and SLOWER on the GPU box: 172 -> 148 / 181 / 328 ms with 2 / 4 / 8 threads for 296 k triangles
+// (allocator and cache-line contention on a host that grants 16 of 256 CPUs).  What did pay is the sparse sweep above and one pass for
+// the three axes: 290 -> 172 ms, and 41 -> 22 ms for the 38 k scene.  The fast build is the one on the GPU: MCPT_BUILD_GPU_PLOC.)
 BNode *sah_build(Arena &A, std::vector<BObj *> &objs, size_t begin, size_t end) {
     BNode *node = A.make();
     const size_t n = end - begin;
@@ -152,46 +147,50 @@ BNode *sah_build(Arena &A, std::vector<BObj *> &objs, size_t begin, size_t end) 
     }
     Box cb = box_empty();
     for (size_t i = begin; i < end; ++i) cb = box_union(cb, centroid(objs[i]->bounds));
-    constexpr int kBins = 32;
+    float lo3[3], scale3[3];
+    bool live[3];
+    for (int ax = 0; ax < 3; ++ax) {
+        const float lo = axis(cb.mn, ax), hi = axis(cb.mx, ax);
+        live[ax] = hi > lo;
+        lo3[ax] = lo;
+        scale3[ax] = live[ax] ? kBins / (hi - lo) : 0.f;
+    }
+    SahBins bins;
+    bins.clear();
+    for (size_t i = begin; i < end; ++i) {
+        const BObj *o = objs[i];
+        for (int ax = 0; ax < 3; ++ax)
+            if (live[ax]) bins.add(ax, sah_bin(o, ax, lo3[ax], scale3[ax]), o->bounds);
+    }
     float best_cost = std::numeric_limits<float>::infinity();
     int best_axis = -1, best_split = -1;
     for (int ax = 0; ax < 3; ++ax) {
-        const float lo = axis(cb.mn, ax), hi = axis(cb.mx, ax);
-        if (!(hi > lo)) continue;
-        Box bb[kBins];
-        int cnt[kBins];
-        for (int b = 0; b < kBins; ++b) {
-            bb[b] = box_empty();
-            cnt[b] = 0;
-        }
-        const float scale = kBins / (hi - lo);
-        for (size_t i = begin; i < end; ++i) {
-            int b = (int)((axis(centroid(objs[i]->bounds), ax) - lo) * scale);
-            b = std::min(std::max(b, 0), kBins - 1);
-            bb[b] = box_union(bb[b], objs[i]->bounds);
-            cnt[b]++;
-        }
+        if (!live[ax]) continue;
+        const Box *bb = bins.bb[ax];
+        const int *cnt = bins.cnt[ax];
+        int idx[kBins], k = 0;  // the populated bins, ascending
+        for (int b = 0; b < kBins; ++b)
+            if (cnt[b]) idx[k++] = b;
         float right_area[kBins];
         int right_cnt[kBins];
         Box acc = box_empty();
         int c = 0;
-        for (int b = kBins - 1; b > 0; --b) {
-            acc = box_union(acc, bb[b]);
-            c += cnt[b];
-            right_area[b] = c ? half_area(acc) : 0.f;
-            right_cnt[b] = c;
+        for (int j = k - 1; j > 0; --j) {  // bins >= idx[j]
+            acc = box_union(acc, bb[idx[j]]);
+            c += cnt[idx[j]];
+            right_area[j] = half_area(acc);
+            right_cnt[j] = c;
         }
         acc = box_empty();
         c = 0;
-        for (int b = 0; b < kBins - 1; ++b) {
-            acc = box_union(acc, bb[b]);
-            c += cnt[b];
-            if (c == 0 || right_cnt[b + 1] == 0) continue;
-            const float cost = half_area(acc) * c + right_area[b + 1] * right_cnt[b + 1];
+        for (int j = 0; j + 1 < k; ++j) {  // split after bin idx[j]
+            acc = box_union(acc, bb[idx[j]]);
+            c += cnt[idx[j]];
+            const float cost = half_area(acc) * c + right_area[j + 1] * right_cnt[j + 1];
             if (cost < best_cost) {
                 best_cost = cost;
                 best_axis = ax;
-                best_split = b;
+                best_split = idx[j];
             }
         }
     }
@@ -199,33 +198,14 @@ BNode *sah_build(Arena &A, std::vector<BObj *> &objs, size_t begin, size_t end) 
     if (best_axis < 0) {
         mid = begin + n / 2;  // all centroids coincide
     } else {
-        const float lo = axis(cb.mn, best_axis), hi = axis(cb.mx, best_axis);
-        const float scale = kBins / (hi - lo);
+        const float lo = lo3[best_axis], scale = scale3[best_axis];
         const int ax = best_axis, split = best_split;
-        auto it = std::stable_partition(objs.begin() + begin, objs.begin() + end, [=](const BObj *o) {
-            int b = (int)((axis(centroid(o->bounds), ax) - lo) * scale);
-            b = std::min(std::max(b, 0), kBins - 1);
-            return b <= split;
-        });
+        auto it = std::stable_partition(objs.begin() + begin, objs.begin() + end, [=](const BObj *o) { return sah_bin(o, ax, lo, scale) <= split; });
         mid = (size_t)(it - objs.begin());
         if (mid == begin || mid == end) mid = begin + n / 2;
     }
-    // (a helper for the left half when both halves are big and one is free; the counter never goes below zero)
-    bool helper = false;
-    if (mid - begin >= 4096 && end - mid >= 4096) {
-        int spare = g_spare_builders.load();
-        while (spare > 0 && !g_spare_builders.compare_exchange_weak(spare, spare - 1)) {}
-        helper = spare > 0;
-    }
-    if (helper) {
-        std::thread t([&]() { node->left = sah_build(A, objs, begin, mid); });
-        node->right = sah_build(A, objs, mid, end);
-        t.join();
-        g_spare_builders.fetch_add(1);
-    } else {
-        node->left = sah_build(A, objs, begin, mid);
-        node->right = sah_build(A, objs, mid, end);
-    }
+    node->left = sah_build(A, objs, begin, mid);
+    node->right = sah_build(A, objs, mid, end);
     node->bounds = box_union(node->left->bounds, node->right->bounds);
     node->area = node->left->area + node->right->area;
     return node;
@@ -505,7 +485,6 @@ void build_sah_over_clusters(int m, const float *cmin4, const float *cmax4, cons
         ptrs[(size_t)i] = &objs[(size_t)i];
     }
     Arena arena;
-    init_builders();
     const BNode *root = sah_build(arena, ptrs, 0, ptrs.size());
     struct Emit {
         const int32_t *cref, *clevels;
@@ -816,7 +795,6 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, 
             }
             std::vector<BObj *> ptrs;
             for (BObj &o : objs) ptrs.push_back(&o);
-            init_builders();
             const BNode *proot = sah_build(arena, ptrs, 0, ptrs.size());
             Flattener PF{hs};
             const int32_t root_ref = PF.flatten(proot, 1);  // (n_tri >= 64: an inner node)
@@ -861,7 +839,6 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, 
             else
                 for (int k = 0; k < d.objects[oi].n_tri; ++k) prims.push_back(&tri_objs[d.objects[oi].first_tri + k]);
         }
-        init_builders();
         phase("instancing, primitive list");
         BNode *r = sah_build(arena, prims, 0, prims.size());
         phase("binned SAH build");
