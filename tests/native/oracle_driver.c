@@ -56,9 +56,14 @@ int main(int argc, char **argv) {
     dir[0] = dir[1] = dir[2] = 0.f; /* the all-zero direction of a total internal reflection */
     orc_intersect(s, N, o, dir, t, prim);
     orc_cast_rays(s, &p, N, o, dir, pix, smp, ch, out);
+    int32_t *vis = malloc(sizeof(int32_t) * (size_t)cam.width * cam.height * 3);
+    if (orc_primary_hits(s, &cam, 1, 3, vis) != 0) return 6; /* primary visibility (the chess geometry pin) */
+    long seen = 0;
+    for (int i = 0; i < cam.width * cam.height * 3; ++i) seen += vis[i] >= 0;
+    free(vis);
     uint8_t *rgba = malloc((size_t)cam.width * cam.height * 4);
     orc_tonemap(fb, (int64_t)cam.width * cam.height, rgba);
-    printf("samples %llu rays %llu mean %.6f hit0 %d\n", (unsigned long long)st.samples, (unsigned long long)st.scene_rays, sum / (cam.width * cam.height * 3), prim[1]);
+    printf("samples %llu rays %llu mean %.6f hit0 %d primary hits %ld\n", (unsigned long long)st.samples, (unsigned long long)st.scene_rays, sum / (cam.width * cam.height * 3), prim[1], seen);
     orc_scene_destroy(s);
     free(tris); free(mats); free(objs); free(env); free(fb); free(rgba);
     return 0;

@@ -1,6 +1,6 @@
 """Randomised consistency run (not part of the test suite): random frame sizes, spp, light samples, roulette rates, pass sizes, pools,
-builders, instancing, culling, rank counts -- every variant must render the frame of the plain configuration of the same scene and
-parameters.  python tools/stress.py [seconds]"""
+builders (host SAH / reference topology / GPU LBVH / GPU PLOC), instancing, culling, the LDS-resident small-scene flavour on and off, rank
+counts -- every variant must render the frame of the plain configuration of the same scene and parameters.  python tools/stress.py [seconds]"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, mcpt_loader
@@ -17,14 +17,17 @@ while time.time() - t0 < budget:
         sd.camera["use_dof"] = int(rng.integers(0, 2))
     kw = dict(spp=spp, seed=int(rng.integers(0, 1000)), n_dir_sample=int(rng.choice([1, 3, 4, 8])), spp_per_pass=int(rng.integers(1, spp + 1)))
     os.environ.pop("MCPT_SKY_CULL", None)
+    os.environ.pop("MCPT_SMALL_SCENE", None)
     ref, st0 = pkg.HipScene(sd, builder="sah", instancing=False).render(**kw)
-    variants = [dict(builder="lbvh"), dict(builder="sah", quantise=0), dict(builder="sah", instancing=True), dict(builder="reference")]
+    variants = [dict(builder="lbvh"), dict(builder="ploc"), dict(builder="sah", quantise=0), dict(builder="sah", instancing=True), dict(builder="reference"),
+                dict(builder="ploc", quantise=0)]
     for v in variants:
         extra = dict(pool_paths=int(rng.choice([0, 3 * 256, 3 * 4096, 3 * 65536])))
-        if rng.random() < 0.5:
-            os.environ["MCPT_SKY_CULL"] = "0"
-        else:
-            os.environ.pop("MCPT_SKY_CULL", None)
+        for knob in ("MCPT_SKY_CULL", "MCPT_SMALL_SCENE"):
+            if rng.random() < 0.5:
+                os.environ[knob] = "0"
+            else:
+                os.environ.pop(knob, None)
         hs = pkg.HipScene(sd, **v)
         nr = int(rng.choice([1, 1, 2, 3, 5]))
         if nr == 1:
