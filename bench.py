@@ -143,7 +143,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # (under a launcher even ONE rank goes through the process group, the RCCL reduce and the device gathering: what a one-GPU box can
+    # exercise of the nccl leg)
+    distributed = "WORLD_SIZE" in os.environ
     if distributed and world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
@@ -334,7 +336,7 @@ def main():
     # ---- CPU baseline: the oracle (a port of the reference path) on this box's host cores, bounded samples:
     # all cores the cgroup grants, and 8 threads (the reference's fixed PARALLELISM, Renderer.cpp:16)
     cpu, cpu8 = None, None
-    if not args.no_cpu_baseline and not distributed:
+    if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only)
         from oracle import oracle as orc
         ncores = host_cores()
         osc = orc.OracleScene(sd)

@@ -69,7 +69,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
     assert p.returncode != 0
     assert "starting 2 ranks" in p.stderr and "--nproc-per-node 2" in p.stderr
-    assert p.stderr.count("bench.py needs a GPU") >= 2
+    assert "bench.py needs a GPU" in p.stderr  # (from at least one rank: the launcher stops the others as soon as the first one fails)
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
     # one rank needs no launcher and says the same
     p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)

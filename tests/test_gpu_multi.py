@@ -126,3 +126,27 @@ def test_bench_refuses_ranks_without_their_own_device(tmp_path):
                         "--width", "64", "--height", "64", "--no-cpu-baseline", "--no-psnr"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert p.returncode != 0
     assert "GPU(s) visible" in p.stderr and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_one_rank_through_rccl(tmp_path):
+    """bench.py as a rank of a one-rank job (`torch.distributed.run --nproc-per-node 1`), backend nccl: process-group set-up on RCCL, the
+    gathering of the ranks' devices, `dist.reduce` of the device framebuffer and the max / sum all-reduces all execute -- with one rank,
+    which is what a one-GPU box can run of that leg (RCCL refuses two ranks on one device).  The PNG equals the plain run's."""
+    import socket
+    common = ["--steps", "1", "--warmup", "1", "--spp-per-step", "4", "--width", "256", "--height", "144", "--no-cpu-baseline", "--no-psnr"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    one = str(tmp_path / "plain.png")
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--save-png", one] + common, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    two = str(tmp_path / "rccl.png")
+    p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                         os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--save-png", two] + common,
+                        capture_output=True, text=True, env=dict(env, MASTER_ADDR="127.0.0.1"), cwd=ROOT, timeout=900)
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    j = json.loads([l for l in p2.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["backend"] == "nccl" and len(j["ranks"]) == 1 and j["ranks"][0]["gcnArchName"].startswith("gfx950")
+    assert open(one, "rb").read() == open(two, "rb").read()
