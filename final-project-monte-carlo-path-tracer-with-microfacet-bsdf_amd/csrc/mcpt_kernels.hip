@@ -1680,16 +1680,18 @@ inline uint32_t blocks(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 // passes the lengths it read right after k_shade (from_host); in the drain phase they are read here.
 __global__ void k_bookkeep(Counters *c, int cur_idx, int from_host, uint32_t n_next, uint32_t n_cont, uint32_t n_direct) {
     const int nxt = cur_idx ^ 1;
+    // The 2 x 32 shard counters of the consumed shadow queue: one lane each, summed over the wave.  (Until round 3 lane 0 walked them in a
+    // loop: 64 dependent global round trips, 115 us per launch of a kernel that sits between k_shade and k_direct on the main stream --
+    // 29 ms of a 650 ms frame.)
+    static_assert(2 * kShadowShards == 64, "one lane per shard counter");
+    HotCounter *const shard = threadIdx.x < kShadowShards ? &c->n_shadow[cur_idx][threadIdx.x] : &c->n_shadow_w[cur_idx][threadIdx.x - kShadowShards];
+    uint32_t n_shadow = shard->v;
+    shard->v = 0;
+    for (int o = 32; o > 0; o >>= 1) n_shadow += (uint32_t)__shfl_xor((int)n_shadow, o);
     switch (threadIdx.x) {  // one lane per field: the global accesses are independent and overlap
     case 0: {
-        uint32_t v = 0;
-        for (uint32_t k = 0; k < kShadowShards; ++k) {
-            v += c->n_shadow[cur_idx][k].v + c->n_shadow_w[cur_idx][k].v;
-            c->n_shadow[cur_idx][k].v = 0;
-            c->n_shadow_w[cur_idx][k].v = 0;
-        }
-        c->tot_shadow += v;
-        c->last_shadow = v;
+        c->tot_shadow += n_shadow;
+        c->last_shadow = n_shadow;
         break;
     }
     case 1: c->tot_shaded += from_host ? n_next : c->n_paths[nxt].v; break;  // (new samples have no records)
