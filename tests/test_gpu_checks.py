@@ -154,3 +154,20 @@ def test_skipped_direct_lighting_is_zero_on_random_scenes(pkg, hip, hip_check):
         hc.close()
     print("\n[direct-skip check] 24 random scenes: %d light samples at skipped vertices, 0 non-zero" % tot_skipped)
     assert tot_skipped > 100000
+
+
+def test_random_variants_render_the_plain_frame(pkg, hip, monkeypatch):
+    """A bounded slice of tools/stress.py inside the suite: 20 seconds of random configurations (frame size, spp, light samples, roulette
+    rate, pass size, pool size, rank count) under every builder (host SAH float / quantised / instanced, reference topology, GPU LBVH, GPU
+    PLOC) with the sky cull and the LDS-resident flavour switched at random: every variant renders the plain configuration's frame (at
+    most 3 box-grazing values apart).  The full run (`python tools/stress.py 240`: 1752 renders, 0 mismatches) is in profiles/r03_stress.txt."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("mcpt_stress", os.path.join(root, "tools", "stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    monkeypatch.chdir(root)
+    spec.loader.exec_module(mod)
+    n, bad = mod.run(20.0, 7)
+    print("\n[stress] %d variant renders, %d mismatches" % (n, bad))
+    assert n >= 30 and bad == 0
