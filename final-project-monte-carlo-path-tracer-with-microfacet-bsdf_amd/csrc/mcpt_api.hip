@@ -1117,8 +1117,8 @@ int upload_scene(const mcpt_scene_desc *desc, HostBuild &hb, int device, mcpt_sc
 #endif
     v.dbg = nullptr;
 #if defined(MCPT_TRAVERSAL_STATS) || defined(MCPT_CHECK_DIRECT_SKIP)
-    if (sc->dbg.alloc(16) == hipSuccess) {
-        (void)hipMemset(sc->dbg.p, 0, 16 * sizeof(unsigned long long));
+    if (sc->dbg.alloc(32) == hipSuccess) {  // (16 reported by mcpt_debug_counters; the statistics build prints the rest at destruction)
+        (void)hipMemset(sc->dbg.p, 0, 32 * sizeof(unsigned long long));
         v.dbg = sc->dbg.p;
     }
 #endif
@@ -1149,8 +1149,11 @@ void mcpt_scene_destroy(mcpt_scene *sc) {
     (void)hipSetDevice(sc->device);
 #if defined(MCPT_TRAVERSAL_STATS) || defined(MCPT_CHECK_DIRECT_SKIP)
     if (sc->dbg.p) {
-        unsigned long long h[16];
+        unsigned long long h[32];
         if (hipMemcpy(h, sc->dbg.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (h[23])
+                std::fprintf(stderr, "[mcpt k_shade stats] %llu waves: %.0f cycles from start to the end of the allocation, of which %.0f in its first half (ballots, first barrier) and %.0f in the second barrier\n",
+                             h[23], (double)h[22] / h[23], (double)h[20] / h[23], (double)h[21] / h[23]);
             if (h[14]) std::fprintf(stderr, "[mcpt direct-skip check] light samples at skipped vertices: %llu, non-zero contributions among them: %llu\n", h[14], h[15]);
             for (int k = 0; k < 2; ++k) {
                 const unsigned long long *d = h + 8 * k;

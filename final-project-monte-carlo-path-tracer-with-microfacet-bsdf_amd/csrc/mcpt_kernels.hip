@@ -1216,6 +1216,9 @@ MCPT_DI float unwind(const RenderConst &C, uint32_t slot, uint32_t depth, float 
 
 __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderConst C, Wave cur, Wave next, Scratch Xs, int cur_idx) {
     __shared__ BlockAllocShared sh;
+#ifdef MCPT_TRAVERSAL_STATS
+    const long long t_wave0 = clock64();
+#endif
     const uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
     // the grid is an upper bound; the list lengths live on the device.  Lanes [0, n_rec) take the records of the list, the next
     // 3 * n_new lanes the new samples (one lane per channel path).
@@ -1383,7 +1386,13 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
                               &C.counters->live[0].v, &C.counters->live[1].v, &C.counters->ended.v};
     const bool sub[9] = {false, false, false, false, false, false, true, true, false};
     uint32_t prefix[9], idx[9];
+#ifdef MCPT_TRAVERSAL_STATS
+    const long long tb0 = clock64();
+#endif
     block_alloc_begin<9>(sh, want, mult, ctr, sub, prefix);
+#ifdef MCPT_TRAVERSAL_STATS
+    const long long tb1 = clock64();
+#endif
 
     float kr = 0.f, ev = 0.f, aw = 0.f, pd = 0.f;
     f3 p2 = mk3(0, 0, 0), wi = mk3(0, 0, 1);
@@ -1405,7 +1414,19 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
         }
     }
 
+#ifdef MCPT_TRAVERSAL_STATS
+    const long long tb2 = clock64();
+#endif
     block_alloc_end<9>(sh, mult, prefix, idx);
+#ifdef MCPT_TRAVERSAL_STATS
+    if (S.dbg && lane_id() == 0) {  // cycles of this wave: in block_alloc_begin (ballots + first barrier), in block_alloc_end (second barrier), since its start
+        const long long tb3 = clock64();
+        atomicAdd(&S.dbg[20], (unsigned long long)(tb1 - tb0));
+        atomicAdd(&S.dbg[21], (unsigned long long)(tb3 - tb2));
+        atomicAdd(&S.dbg[22], (unsigned long long)(tb3 - t_wave0));
+        atomicAdd(&S.dbg[23], 1ull);
+    }
+#endif
     if (done) C.free_slots[idx[0] & C.free_mask] = slot;
     if (!do_shade) return;
     if (ends_here) {
