@@ -41,6 +41,11 @@ static_assert(sizeof(QNode) == 32, "QNode must be 32 bytes");
 
 // Traversal-side triangle record (48 bytes, three 16-byte loads): what Triangle::getIntersection reads
 // (Triangle.hpp:222-252): v0, e1, e2.
+// TriGeom::mat_bits / SphereRec::mat_bits / the hit record's fourth word: material index and two flags of the material, so that k_shade
+// knows them with the hit instead of one dependent load later
+constexpr uint32_t kMatEmissive = 0x80000000u;  // the material emits (Material::hasEmission)
+constexpr uint32_t kMatTextured = 0x40000000u;  // triangles only: the material is textured, the shading needs the barycentrics (Triangle.hpp:248)
+constexpr uint32_t kMatIndexMask = 0x3fffffffu;
 struct alignas(16) TriGeom {
     float v0[3];
     float e1x;

@@ -947,7 +947,7 @@ MCPT_DI void primary_finish(const DevScene &S, const RenderConst &C, const Wave 
             result[(size_t)s * 3 + 1] = env.y;
             result[(size_t)s * 3 + 2] = env.z;
         } else {
-            const int mat = (int)(tr.mat_bits & 0x7fffffffu);
+            const int mat = (int)(tr.mat_bits & kMatIndexMask);
             if (tr.mat_bits >> 31) {  // depth-0 emitter, Scene.cpp:102-107
                 const MaterialRec &M = S.mats[mat];
                 f3 n;
@@ -1204,6 +1204,9 @@ MCPT_DI bool direct_is_zero(const DevScene &S, const MaterialRec &m, f3 q, f3 n,
 // HBM; when the path ends the stack is unwound with exactly the reference's float expressions.
 // ------------------------------------------------------------------------------------------------
 MCPT_DI float unwind(const RenderConst &C, uint32_t slot, uint32_t depth, float X) {
+#ifdef MCPT_ABL_UNWIND
+    return X;
+#endif
     for (int lvl = (int)depth - 1; lvl >= 0; --lvl) {
         const float4 e = C.stack[(size_t)lvl * C.pool + slot];
         float l_ind;
@@ -1235,6 +1238,7 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     double hit_t = 0;
     int32_t hit_prim = -1;
     uint32_t hit_mat = 0;
+    float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = make_float4(0.f, 0.f, 1.f, 0.f);
 
     if (valid) {
         uint4 r0;
@@ -1261,6 +1265,14 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
             slot = __float_as_uint(r1.w);
         }
         pq = (int)((flags >> 20) & 1u);
+        // everything the record points to is requested at once, before any of it is looked at: the hit, and the ray itself (a surface hit
+        // needs both vectors, a miss the direction: only a path that ends on the depth limit asks for nothing)
+        uint4 h = make_uint4(0u, 0u, 0xffffffffu, 0u);
+        if (!(flags & kTerminate)) {
+            h = cur.hit[ray_idx];
+            ro4 = cur.ray_o[ray_idx];
+            rd4 = cur.ray_d[ray_idx];
+        }
         path_key(C, pid, pq, key, ch);
 
         if (!(flags & kFresh)) {
@@ -1280,13 +1292,12 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
                 X = l_dir;  // Scene.cpp:129-131,156-158: returned unclamped
                 finished = true;
             } else {
-                const uint4 h = cur.hit[ray_idx];
                 hit_t = __longlong_as_double((long long)(((unsigned long long)h.y << 32) | h.x));
                 hit_prim = (int32_t)h.z;
                 hit_mat = h.w;
                 const bool surface = hit_prim >= 0 && !(hit_mat >> 31);  // Scene.cpp:135,162
                 if (!surface) {
-                    const f3 wi = ld3(cur.ray_d[ray_idx]);
+                    const f3 wi = ld3(rd4);
                     const float env = comp(sample_env(S, wi), ch);  // Scene.cpp:145-149,172-176
                     const float l_ind = env * r1.x * C.inv_rr;
                     X = clampf(0, 15, l_dir) + clampf(0, 5, l_ind);
@@ -1296,19 +1307,20 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
                     finished = true;
                     overflow = true;
                 } else {
+#ifndef MCPT_ABL_PUSH
                     C.stack[(size_t)depth * C.pool + slot] = make_float4(clampf(0, 15, l_dir), r1.x, r1.y, r1.z);
+#endif
                     depth += 1;
                     pushed = true;
                     do_shade = true;
                 }
             }
         } else {
-            const uint4 h = cur.hit[ray_idx];
             hit_t = __longlong_as_double((long long)(((unsigned long long)h.y << 32) | h.x));
             hit_prim = (int32_t)h.z;
             hit_mat = h.w;
             if (hit_prim < 0) {
-                X = comp(sample_env(S, ld3(cur.ray_d[ray_idx])), ch);  // Scene.cpp:88-95
+                X = comp(sample_env(S, ld3(rd4)), ch);  // Scene.cpp:88-95
                 finished = true;
             } else {
                 do_shade = true;  // the depth-0 emitter test needs the normal; done below
@@ -1319,15 +1331,15 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     // ---- vertex set-up for lanes that shade
     f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), p = mk3(0, 0, 0), n = mk3(0, 0, 1), wo = mk3(0, 0, -1);
     f2 uv{0.f, 0.f};
-    const int mat_id = (int)(hit_mat & 0x7fffffffu);
+    const int mat_id = (int)(hit_mat & kMatIndexMask);
     if (do_shade) {
-        ro = ld3(cur.ray_o[ray_idx]);
-        rd = ld3(cur.ray_d[ray_idx]);
+        ro = ld3(ro4);
+        rd = ld3(rd4);
         if (hit_prim < S.n_tri) {
             const TriShade ts = S.tri_shade[hit_prim];
             n = mk3(ts.n[0], ts.n[1], ts.n[2]);
             p = ro + rd * (float)hit_t;  // Triangle.hpp:245 / Ray.hpp:21
-            if (S.mats[mat_id].textured) {  // Triangle.hpp:248: recompute the barycentrics of the recorded hit
+            if (hit_mat & kMatTextured) {  // Triangle.hpp:248: recompute the barycentrics of the recorded hit (the flag travels with the hit)
                 double t, u, v;
                 const Ray rr = make_ray(ro, rd);
                 if (tri_hit(S.tri_geom[hit_prim], rr, t, u, v)) {
@@ -1352,6 +1364,9 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     // ---- finish: unwind the clamp stack and publish the path value
     if (finished) {
         X = unwind(C, slot, depth, X);
+#ifdef MCPT_ABL_RESULT
+        if (X == 12345.678f)
+#endif
         (pq ? C.result[1] : C.result[0])[pid] = X;
     }
 
@@ -1431,12 +1446,20 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     if (!do_shade) return;
     if (ends_here) {
         const float l_dir = inside ? (float)((1. - (double)kr) * (double)0.f) : kr * 0.f;  // Scene.cpp:116-119 with l_dir == 0
-        (pq ? C.result[1] : C.result[0])[pid] = unwind(C, slot, depth, l_dir);
+        const float Xe = unwind(C, slot, depth, l_dir);
+#ifdef MCPT_ABL_RESULT
+        if (Xe == 12345.678f)
+#endif
+        (pq ? C.result[1] : C.result[0])[pid] = Xe;
         return;
     }
     const uint32_t j = idx[1], rj = idx[2], dj = idx[3];
 
+#ifdef MCPT_ABL_VTX
+    if (need_direct && q.x == 12345.678f) {
+#else
     if (need_direct) {  // work-list entry for k_direct (Scene::directLighting runs there, one lane per light sample)
+#endif
         Xs.vtx0[dj] = make_float4(q.x, q.y, q.z, uv.x);
         Xs.vtx1[dj] = make_float4(n.x, n.y, n.z, uv.y);
         Xs.vtx2[dj] = make_float4(wo.x, wo.y, wo.z, __uint_as_float((uint32_t)mat_id | ((uint32_t)ch << 16) | (inside ? (1u << 18) : 0u) |

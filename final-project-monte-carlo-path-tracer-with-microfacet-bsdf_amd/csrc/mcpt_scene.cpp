@@ -620,7 +620,7 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, 
             s.radius = o.radius;
             s.radius2 = o.radius * o.radius;
             s.mat = o.material;
-            s.mat_bits = (uint32_t)o.material | (hs.materials[o.material].hasEmission ? 0x80000000u : 0u);
+            s.mat_bits = (uint32_t)o.material | (hs.materials[o.material].hasEmission ? kMatEmissive : 0u);
             B.prim = d.n_triangles + oi;
             hs.sphere_objects.push_back(oi);
             const V3 c = ld(o.center);
@@ -660,7 +660,7 @@ int build_host_scene(const mcpt_scene_desc &d, HostScene &hs, const char **err, 
                 g.e2xy[0] = e2.x;
                 g.e2xy[1] = e2.y;
                 g.e2z = e2.z;
-                g.mat_bits = (uint32_t)o.material | (hs.materials[o.material].hasEmission ? 0x80000000u : 0u);
+                g.mat_bits = (uint32_t)o.material | (hs.materials[o.material].hasEmission ? kMatEmissive : 0u) | (hs.materials[o.material].textured ? kMatTextured : 0u);
                 TriShade &s = hs.tri_shade[ti];
                 std::memset(&s, 0, sizeof s);
                 store3(s.n, n);
