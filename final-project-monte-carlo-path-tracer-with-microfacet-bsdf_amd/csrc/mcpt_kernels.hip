@@ -1204,9 +1204,6 @@ MCPT_DI bool direct_is_zero(const DevScene &S, const MaterialRec &m, f3 q, f3 n,
 // HBM; when the path ends the stack is unwound with exactly the reference's float expressions.
 // ------------------------------------------------------------------------------------------------
 MCPT_DI float unwind(const RenderConst &C, uint32_t slot, uint32_t depth, float X) {
-#ifdef MCPT_ABL_UNWIND
-    return X;
-#endif
     for (int lvl = (int)depth - 1; lvl >= 0; --lvl) {
         const float4 e = C.stack[(size_t)lvl * C.pool + slot];
         float l_ind;
@@ -1307,9 +1304,7 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
                     finished = true;
                     overflow = true;
                 } else {
-#ifndef MCPT_ABL_PUSH
                     C.stack[(size_t)depth * C.pool + slot] = make_float4(clampf(0, 15, l_dir), r1.x, r1.y, r1.z);
-#endif
                     depth += 1;
                     pushed = true;
                     do_shade = true;
@@ -1364,9 +1359,6 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     // ---- finish: unwind the clamp stack and publish the path value
     if (finished) {
         X = unwind(C, slot, depth, X);
-#ifdef MCPT_ABL_RESULT
-        if (X == 12345.678f)
-#endif
         (pq ? C.result[1] : C.result[0])[pid] = X;
     }
 
@@ -1446,20 +1438,12 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
     if (!do_shade) return;
     if (ends_here) {
         const float l_dir = inside ? (float)((1. - (double)kr) * (double)0.f) : kr * 0.f;  // Scene.cpp:116-119 with l_dir == 0
-        const float Xe = unwind(C, slot, depth, l_dir);
-#ifdef MCPT_ABL_RESULT
-        if (Xe == 12345.678f)
-#endif
-        (pq ? C.result[1] : C.result[0])[pid] = Xe;
+        (pq ? C.result[1] : C.result[0])[pid] = unwind(C, slot, depth, l_dir);
         return;
     }
     const uint32_t j = idx[1], rj = idx[2], dj = idx[3];
 
-#ifdef MCPT_ABL_VTX
-    if (need_direct && q.x == 12345.678f) {
-#else
     if (need_direct) {  // work-list entry for k_direct (Scene::directLighting runs there, one lane per light sample)
-#endif
         Xs.vtx0[dj] = make_float4(q.x, q.y, q.z, uv.x);
         Xs.vtx1[dj] = make_float4(n.x, n.y, n.z, uv.y);
         Xs.vtx2[dj] = make_float4(wo.x, wo.y, wo.z, __uint_as_float((uint32_t)mat_id | ((uint32_t)ch << 16) | (inside ? (1u << 18) : 0u) |
