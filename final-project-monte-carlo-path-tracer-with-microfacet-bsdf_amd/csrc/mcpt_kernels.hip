@@ -1279,6 +1279,12 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
                 if (C.n_dir == 4) {  // one 16-byte request instead of four dwords; same sum, same order (Scene.cpp:76 `l_dir +=`)
                     const float4 c4 = reinterpret_cast<const float4 *>(cur.contrib)[i];
                     dl = (((dl + c4.x) + c4.y) + c4.z) + c4.w;
+                } else if ((C.n_dir & 3) == 0) {  // (32 light samples, as the README labels the chess render: 8 requests instead of 32)
+                    const float4 *c4 = reinterpret_cast<const float4 *>(cur.contrib) + (size_t)i * (uint32_t)(C.n_dir >> 2);
+                    for (int k = 0; k < (C.n_dir >> 2); ++k) {
+                        const float4 v = c4[k];
+                        dl = (((dl + v.x) + v.y) + v.z) + v.w;
+                    }
                 } else {
                     for (int k = 0; k < C.n_dir; ++k) dl += cur.contrib[(size_t)i * C.n_dir + k];  // Scene.cpp:76 `l_dir +=`, in order
                 }
@@ -1502,6 +1508,9 @@ __global__ __launch_bounds__(kBlock, MCPT_DIRECT_WAVES) void k_direct(DevScene S
         if (n_dir == 4u) {  // the reference's fixed count (Scene.hpp:28): no division
             dj = g >> 2;
             k = g & 3u;
+        } else if ((n_dir & (n_dir - 1u)) == 0u) {  // another power of two (32, the README's count): still no division
+            dj = g >> (uint32_t)(__ffs((int)n_dir) - 1);
+            k = g & (n_dir - 1u);
         } else {
             dj = g / n_dir;
             k = g - dj * n_dir;
