@@ -154,7 +154,12 @@ struct Knobs {
     int pools = 1;              // MCPT_POOLS=2: two pools on two host threads
     int drain_batch = 4;        // MCPT_DRAIN_BATCH: iterations per host sync in the drain tail
     uint64_t pool_min_work = 1ull << 20;  // MCPT_POOL_MIN_WORK: smallest pass (samples) that uses two pools
-    uint32_t shadow_grid_per_cu = 1024;   // MCPT_SHADOW_GRID_PER_CU: grid cap of k_trace_shadow
+    // Grid caps, in workgroups per CU.  Every workgroup of k_trace_shadow computes the prefix sums of the queue's shards first, and the
+    // LDS-resident flavours copy the scene into LDS first: with 128 / 64 per CU a workgroup strides over several chunks for one such
+    // prologue and the hardware still balances uneven rays (round 3, A/B: cornell_rc 784^2 471 -> 490 Msamples/s, DEMO 1080p 873 -> 924,
+    // k_trace_shadow -11 %, k_direct -14 %; chess within noise for 64..1024.  8 per CU, a persistent grid, was 30 % slower in round 1).
+    uint32_t shadow_grid_per_cu = 128;    // MCPT_SHADOW_GRID_PER_CU: grid cap of k_trace_shadow
+    uint32_t direct_grid_per_cu = 64;     // MCPT_DIRECT_GRID_PER_CU: grid cap of k_direct for LDS-resident scenes (0: none)
     // pure test hooks, compiled only into the checking build (-DMCPT_TEST_HOOKS, libmcpt_hip_check.so)
     uint32_t ring_start = 0;    // MCPT_RING_START: the free ring's counters start here (exercises the 2^32 wrap)
     int host_delay_us = 0;      // MCPT_HOST_DELAY_US: a slow host
@@ -173,6 +178,7 @@ struct Knobs {
         if ((v = std::getenv("MCPT_DRAIN_BATCH"))) drain_batch = std::max(1, std::atoi(v));
         if ((v = std::getenv("MCPT_POOL_MIN_WORK"))) pool_min_work = (uint64_t)std::max(1, std::atoi(v));
         if ((v = std::getenv("MCPT_SHADOW_GRID_PER_CU"))) shadow_grid_per_cu = (uint32_t)std::max(1, std::atoi(v));
+        if ((v = std::getenv("MCPT_DIRECT_GRID_PER_CU"))) direct_grid_per_cu = (uint32_t)std::max(0, std::atoi(v));
 #ifdef MCPT_TEST_HOOKS
         if ((v = std::getenv("MCPT_RING_START"))) ring_start = (uint32_t)std::strtoul(v, nullptr, 0);
         if ((v = std::getenv("MCPT_HOST_DELAY_US"))) host_delay_us = std::atoi(v);
@@ -522,7 +528,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
                 T.end(ev, K_SHADE, st);
                 launch_bookkeep(w.counters.p, cur, false, 0, 0, 0, st);
                 ev = T.begin(st);
-                launch_direct(sc->view, C, nx, w.scratch(), nxt, n_cur_max, st);
+                launch_direct(sc->view, C, nx, w.scratch(), nxt, n_cur_max, K.direct_grid_per_cu, st);
                 T.end(ev, K_DIRECT, st);
                 if (C.enable_shadow) {
                     ev = T.begin(st);
@@ -600,7 +606,7 @@ int run_wavefront(mcpt_scene *sc, PoolCtx &ctx, const RenderConst &C0, const Cam
         if (ctx.side[1]) HIP_TRY(hipEventRecord(ctx.book, st));
         if (grid_direct > 0) {
             ev = T.begin(st);
-            launch_direct(sc->view, C, nx, w.scratch(), nxt, grid_direct, st);
+            launch_direct(sc->view, C, nx, w.scratch(), nxt, grid_direct, K.direct_grid_per_cu, st);
             T.end(ev, K_DIRECT, st);
             if (C.enable_shadow) {
                 ev = T.begin(st);

@@ -194,7 +194,7 @@ void launch_trace_closest(const DevScene &S, uint32_t n, const uint32_t *n_dev, 
 // Direct lighting (Scene::directLighting, Scene.cpp:56-82) for the n_vertices entries of the k_direct work list:
 // one lane per (vertex, light sample); fills next.contrib and appends the non-zero samples to the shadow queue.  The list
 // length is read on the device; the grid (n_vertices_grid vertices) strides over it.
-void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_grid, hipStream_t s);
+void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_grid, uint32_t small_per_cu, hipStream_t s);
 // Shadow queue (lengths in counters->n_shadow / n_shadow_w, together at most n_max; arrays of `cap` entries): zeroes
 // contrib[] of invisible samples.
 void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, uint32_t cap, Scratch X,

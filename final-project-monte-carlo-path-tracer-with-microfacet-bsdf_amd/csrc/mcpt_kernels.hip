@@ -1832,9 +1832,11 @@ void launch_trace_closest(const DevScene &S, uint32_t n, const uint32_t *n_dev, 
                         ray_o, ray_d, hit, rl);
 }
 
-void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_grid, hipStream_t s) {
+void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X, int next_idx, uint32_t n_vertices_grid, uint32_t small_per_cu, hipStream_t s) {
     if (n_vertices_grid == 0) return;
-    const dim3 g(blocks(n_vertices_grid * (uint32_t)C.n_dir)), b(kBlock);
+    dim3 g(blocks(n_vertices_grid * (uint32_t)C.n_dir)), b(kBlock);
+    // (SMALL: every workgroup first copies the scene into LDS; a capped grid lets it stride over several chunks of the list for one copy)
+    if (S.small && small_per_cu) g.x = std::min<uint32_t>(g.x, 256u * small_per_cu);
     if (S.small) hipLaunchKernelGGL((k_direct<true>), g, b, 0, s, S, C, next, X, next_idx);
     else hipLaunchKernelGGL((k_direct<false>), g, b, 0, s, S, C, next, X, next_idx);
 }
@@ -1842,8 +1844,8 @@ void launch_direct(const DevScene &S, const RenderConst &C, Wave next, Scratch X
 void launch_trace_shadow(const DevScene &S, const Counters *counters, int next_idx, uint32_t n_max, uint32_t cap, Scratch X,
                          float *contrib, uint32_t per_cu, const RetryList &rl, hipStream_t s) {
     if (n_max == 0) return;
-    // The queue length is only known on the device.  The grid covers the upper bound (capped at 1024 workgroups per
-    // CU, far more than are resident, so the hardware balances uneven rays dynamically: a persistent 8-per-CU grid
+    // The queue length is only known on the device.  The grid covers the upper bound, capped at `per_cu` workgroups per CU (Knobs:
+    // 128, far more than are resident, so the hardware balances uneven rays dynamically: a persistent 8-per-CU grid
     // was 30 % slower on the Cornell box); workgroups past the end of the queue exit at once, longer queues stride.
     const dim3 g(std::min<uint32_t>(blocks(n_max), 256u * per_cu)), b(kBlock);
     MCPT_STACK_DISPATCH(S.height, k_trace_shadow,
