@@ -77,6 +77,31 @@ def test_without_shadows_and_with_many_light_samples(pkg, hip, monkeypatch):
         assert (sa.shadow_rays == 0) == (not shadow)
 
 
+@pytest.mark.parametrize("n_dir", [8, 12])
+def test_light_sample_counts_that_are_multiples_of_four(pkg, oracle, hip, monkeypatch, n_dir):
+    """n_dir 8 (a power of two: k_direct splits its index with a shift) and 12 (k_shade sums the contributions from 16-byte loads, in the
+    reference's order): the oracle's frame."""
+    sd = pkg.scenes.cornell_demo(64, 48, 3)
+    fb, st = _render(hip, sd, monkeypatch, True, spp=3, seed=4, n_dir_sample=n_dir)
+    ref, so = oracle.OracleScene(sd).render(spp=3, seed=4, n_dir_sample=n_dir)
+    differing = int((~((fb == ref) | (np.isnan(fb) & np.isnan(ref)))).sum())
+    assert differing <= 3 and st.vertices == so.vertices and st.direct_vertices * n_dir >= st.shadow_rays > 0
+
+
+def test_grid_caps_change_no_result(pkg, hip, monkeypatch):
+    """k_trace_shadow and k_direct stride over their queues with whatever grid they get (MCPT_SHADOW_GRID_PER_CU, MCPT_DIRECT_GRID_PER_CU:
+    one workgroup per CU here, i.e. every workgroup walks many chunks)."""
+    for scene in (pkg.scenes.cornell_demo(160, 120, 4), pkg.scenes.chess_scene(width=160, height=90, spp=4)):
+        monkeypatch.delenv("MCPT_SHADOW_GRID_PER_CU", raising=False)
+        monkeypatch.delenv("MCPT_DIRECT_GRID_PER_CU", raising=False)
+        a, sa = hip.HipScene(scene).render(spp=4, seed=9)
+        monkeypatch.setenv("MCPT_SHADOW_GRID_PER_CU", "1")
+        monkeypatch.setenv("MCPT_DIRECT_GRID_PER_CU", "1")
+        b, sb = hip.HipScene(scene).render(spp=4, seed=9)
+        assert np.array_equal(a, b, equal_nan=True)
+        assert all(getattr(sa, k) == getattr(sb, k) for k in COUNTERS)
+
+
 def test_scene_beyond_the_limits_is_not_lds_resident(pkg, hip):
     """65 triangles: one more than the SMALL kernels hold."""
     s = pkg.scenes
