@@ -406,6 +406,22 @@ def test_full_size_config2(pkg, oracle, hip):
     assert np.corrcoef(a.ravel(), b.ravel())[0, 1] > 0.97  # (measured 0.981: the oracle frame has 128 spp per pixel, the blocks 16 384)
 
 
+def test_largest_pass_path_ids_beyond_2_to_the_31(pkg, hip, monkeypatch):
+    """The largest pass the library forms: path ids (pixel x sample-of-the-pass x channel) are 32-bit and a pass is cut so that they stay
+    below 2^32 (render_impl).  A 3840x2160 chess frame with 128 spp in ONE pass has ids up to 3.18e9 -- beyond 2^31, where a signed index
+    anywhere in the kernels would show -- and must equal the same samples rendered in four passes of 32 (ids below 2^30) bit for bit, with the
+    same work counters.  A request for 512 spp per pass at this size is cut to 128 by the library itself."""
+    monkeypatch.setenv("MCPT_SKY_CULL", "0")  # every pixel is traced, so the ids really reach 3840 * 2160 * 128 * 3
+    sd = pkg.scenes.chess_scene(width=3840, height=2160, spp=128)
+    hs = hip.HipScene(sd)
+    one, s1 = hs.render(spp=128, seed=2, spp_per_pass=512)   # cut to 128: one pass
+    four, s4 = hs.render(spp=128, seed=2, spp_per_pass=32)
+    assert s1.samples == s4.samples == 3840 * 2160 * 128
+    assert all(getattr(s1, k) == getattr(s4, k) for k in ("vertices", "shaded", "closest_rays", "shadow_rays", "direct_vertices", "ref_scene_rays"))
+    assert np.array_equal(one, four, equal_nan=True)
+    assert np.isfinite(one).mean() > 0.9999 and np.nanmean(one) > 0.05  # (the reference's own NaN / inf path values exist here as in the oracle's frames)
+
+
 def test_primary_visibility_equals_the_oracles(pkg, oracle, hip):
     """What tests/test_chess_geometry_pin.py pins against the reference's chess image is the ORACLE's primary visibility (camera rays
     with depth of field -> the primitive each one hits).  The HIP path gives the same answer, ray for ray: mcpt_camera_rays +
