@@ -1160,6 +1160,9 @@ void mcpt_scene_destroy(mcpt_scene *sc) {
             if (h[23])
                 std::fprintf(stderr, "[mcpt k_shade stats] %llu waves: %.0f cycles from start to the end of the allocation, of which %.0f in its first half (ballots, first barrier) and %.0f in the second barrier\n",
                              h[23], (double)h[22] / h[23], (double)h[20] / h[23], (double)h[21] / h[23]);
+            if (h[24] + h[25] + h[26] + h[27] + h[28])
+                std::fprintf(stderr, "[mcpt k_shade stats] waves by the number of material types among their shading lanes: 0: %llu, 1: %llu, 2: %llu, 3: %llu, 4: %llu; shading lanes %llu\n",
+                             h[24], h[25], h[26], h[27], h[28], h[29]);
             if (h[14]) std::fprintf(stderr, "[mcpt direct-skip check] light samples at skipped vertices: %llu, non-zero contributions among them: %llu\n", h[14], h[15]);
             for (int k = 0; k < 2; ++k) {
                 const unsigned long long *d = h + 8 * k;

@@ -1439,6 +1439,15 @@ __global__ __launch_bounds__(kShadeBlock, 8) void k_shade(DevScene S, RenderCons
         atomicAdd(&S.dbg[22], (unsigned long long)(tb3 - t_wave0));
         atomicAdd(&S.dbg[23], 1ull);
     }
+    if (S.dbg) {  // material divergence: how many of the four material types the shading lanes of this wave hold
+        int nd = 0;
+        for (int t = 0; t < 4; ++t) nd += __ballot(do_shade && m.type == t) != 0ull ? 1 : 0;
+        const unsigned long long ms = __ballot(do_shade);
+        if (lane_id() == 0) {
+            atomicAdd(&S.dbg[24 + nd], 1ull);
+            atomicAdd(&S.dbg[29], (unsigned long long)__popcll(ms));
+        }
+    }
 #endif
     if (done) C.free_slots[idx[0] & C.free_mask] = slot;
     if (!do_shade) return;
