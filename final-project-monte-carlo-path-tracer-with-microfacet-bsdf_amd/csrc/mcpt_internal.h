@@ -52,7 +52,7 @@ struct alignas(16) TriGeom {
     float e1yz[2];
     float e2xy[2];
     float e2z;
-    uint32_t mat_bits;  // material index | emissive << 31 (carried into the hit record: saves k_shade two dependent loads)
+    uint32_t mat_bits;  // material index | kMatTextured | kMatEmissive (carried into the hit record: saves k_shade its dependent material loads)
     int32_t pad[2];
 };
 static_assert(sizeof(TriGeom) == 48, "TriGeom must be 48 bytes");
@@ -72,7 +72,7 @@ struct alignas(16) SphereRec {  // Sphere.hpp:14-18
     float radius;
     float radius2;
     int32_t mat;
-    uint32_t mat_bits;  // material index | emissive << 31
+    uint32_t mat_bits;  // material index | kMatEmissive
     int32_t pad;
 };
 static_assert(sizeof(SphereRec) == 32, "SphereRec must be 32 bytes");

@@ -179,7 +179,7 @@ MCPT_DI void stage_small_lights(DevScene &S, SmallLightLds &L) {
 struct TraceResult {
     double t;
     int32_t prim;
-    uint32_t mat_bits;  // closest hit: material index | emissive << 31
+    uint32_t mat_bits;  // closest hit: material index | kMatTextured | kMatEmissive (TriGeom::mat_bits)
     bool visible;       // shadow queries only
     bool dropped;       // retry flavour: a stack entry was lost, the result is void (the ray goes to the retrace list)
 };
@@ -531,7 +531,7 @@ MCPT_DI void retry_finish(const RetryList &rl) {
     }
 }
 
-MCPT_DI uint4 pack_hit(double t, int32_t prim, uint32_t mat_bits) {  // {t lo, t hi, prim, material | emissive << 31}
+MCPT_DI uint4 pack_hit(double t, int32_t prim, uint32_t mat_bits) {  // {t lo, t hi, prim, TriGeom::mat_bits}
     const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
     return make_uint4((uint32_t)tb, (uint32_t)(tb >> 32), (uint32_t)prim, mat_bits);
 }
