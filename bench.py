@@ -53,7 +53,7 @@ def parse_args():
                     help="chess_high: conf.json with model_quality high honoured (296 k triangles; the shipped executable cannot reach it)")
     ap.add_argument("--pool-paths", type=int, default=0)
     ap.add_argument("--pass-steps", type=int, default=1,
-                    help="the library renders in passes of this many steps' samples (its per-pass result buffer); measured: no effect with the 60 Mi-path pool")
+                    help="the library renders in passes of this many steps' samples times the rank count (its per-pass result buffer; tools/pass_size.py: 256 spp per rank-share of the frame is within 1 % of the best)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=8, help="spp of the bounded CPU-baseline sample (full frame) on all cores; the 8-thread leg uses half")
     ap.add_argument("--serialized", action="store_true",

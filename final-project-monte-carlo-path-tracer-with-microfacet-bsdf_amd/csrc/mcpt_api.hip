@@ -737,36 +737,53 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
         }
     }
 
-    int s_pass_req = p.spp_per_pass > 0 ? p.spp_per_pass : 32;  // the caller's pass size: what the result buffer is sized for
-    while ((uint64_t)n_pix * s_pass_req * 3ull > 0xfffffff0ull && s_pass_req > 1) s_pass_req /= 2;
-    const int s_pass = std::min(s_pass_req, p.spp);
     const int max_depth = derive_max_depth(p);
     // default: the smallest pool within 1 % of the best rate.  Measured on the chess frame (round 3, A/B on one box): 40 Mi paths 5031-5045,
     // 48 Mi 5061, 60 Mi 5052-5066 Msamples/s (round 2: 28 Mi 4467, 40 Mi 4557, 60 Mi 4617, 80 Mi 4605); 40 Mi paths are 38 GB of workspace
     uint64_t pool64 = p.pool_paths > 0 ? (uint64_t)p.pool_paths : (40ull << 20);
     pool64 = std::max<uint64_t>(pool64, 3 * 256);
-    // keep the clamp stack within 48 GiB
-    while (pool64 * (uint64_t)max_depth * 16ull > (48ull << 30) && pool64 > 3 * 4096) pool64 /= 2;
-    // light-sample indices (record * n_dir + k) are 32-bit
-    while (pool64 * (uint64_t)p.n_dir_sample > (1ull << 31) && pool64 > 3 * 4096) pool64 /= 2;
-    pool64 = std::min<uint64_t>(pool64, std::max<uint64_t>(3ull * n_pix * (uint64_t)s_pass, 3 * 256));
-    // ... and the workspace within 80 % of the memory that is free now plus what the existing workspace already holds (other
-    // tenants of the GPU, a second scene): a smaller pool is slower, never wrong
+    // The pass size: what the caller asks for, or (spp_per_pass 0) one chosen here.  Only two passes are in flight (one result half each), and
+    // the tail of a pass -- a few long paths -- holds its half for some twenty iterations: a pass has to carry many pools' worth of samples
+    // or the pool runs half empty between passes.  Measured (tools/pass_size.py, chess 1080p spp 2048; the pool holds 13.4 M samples): 1.2 M
+    // traced pixels x 32 spp (3x the pool) 4263 Msamples/s, x 64 4684, x 128 4907, x 256 4997, x 512 5010, x 1024 / 2048 4880 (the result buffer
+    // grows with the pass); one rank of eight (0.15 M pixels): 32 spp 2317, 256 4282, 512 4610, 1024 4732, 2048 4769.  Chosen: the power
+    // of two that makes a pass at least 24 pools' worth of samples, between 32 spp and the call's own spp, within a quarter of the free memory.
+    // (device memory this call may use: what is free now plus what this scene's workspace and result buffer already hold; other tenants
+    // of the GPU, a second scene, replicas of one group that share the device -- a rehearsal on a one-GPU box -- each take their share)
+    uint64_t have = 0;
+    bool have_mem = false;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             if (sc->knobs.fake_free_mb) free_b = std::min<size_t>(free_b, (size_t)sc->knobs.fake_free_mb << 20);  // (test hook)
             uint64_t held = 0;
             for (int k = 0; k < mcpt_scene::kMaxPools; ++k) held += (uint64_t)sc->pools[k].ws.pool * bytes_per_pool_path(sc->pools[k].ws.n_dir, sc->pools[k].ws.max_depth);
-            const uint64_t result_b = (uint64_t)n_pix * s_pass_req * 3ull * 4ull * 2ull;
-            uint64_t have = (uint64_t)free_b + held + sc->shared.result.bytes();
-            // replicas of one group that share this device (a rehearsal on a one-GPU box) size their pools at the same time, each
-            // from the same "free" figure: every one of them may take its share only
-            have /= (uint64_t)std::max(1, sc->device_sharers);
-            const uint64_t budget = have * 8 / 10 > result_b ? have * 8 / 10 - result_b : 0;
-            const uint64_t per = bytes_per_pool_path(p.n_dir_sample, max_depth);
-            while (pool64 * per > budget && pool64 > 3 * 4096) pool64 /= 2;
+            have = ((uint64_t)free_b + held + sc->shared.result.bytes()) / (uint64_t)std::max(1, sc->device_sharers);
+            have_mem = true;
         }
+    }
+    int s_pass_req = p.spp_per_pass;  // what the result buffer is sized for
+    if (s_pass_req <= 0) {
+        const uint64_t want = 24ull * (pool64 / 3) / std::max<uint32_t>(n_pix, 1u) + 1ull;
+        int cap = 32;
+        while (cap < p.spp && cap < (1 << 20)) cap *= 2;  // (no larger than the call needs: the buffer of a short call stays small)
+        s_pass_req = 32;
+        while ((uint64_t)s_pass_req < want && s_pass_req < cap) s_pass_req *= 2;
+        if (have_mem) while (s_pass_req > 32 && (uint64_t)n_pix * s_pass_req * 3ull * 4ull * 2ull > have / 4) s_pass_req /= 2;
+    }
+    while ((uint64_t)n_pix * s_pass_req * 3ull > 0xfffffff0ull && s_pass_req > 1) s_pass_req /= 2;
+    const int s_pass = std::min(s_pass_req, p.spp);
+    // keep the clamp stack within 48 GiB
+    while (pool64 * (uint64_t)max_depth * 16ull > (48ull << 30) && pool64 > 3 * 4096) pool64 /= 2;
+    // light-sample indices (record * n_dir + k) are 32-bit
+    while (pool64 * (uint64_t)p.n_dir_sample > (1ull << 31) && pool64 > 3 * 4096) pool64 /= 2;
+    pool64 = std::min<uint64_t>(pool64, std::max<uint64_t>(3ull * n_pix * (uint64_t)s_pass, 3 * 256));
+    // ... and the workspace within 80 % of that memory: a smaller pool is slower, never wrong
+    if (have_mem) {
+        const uint64_t result_b = (uint64_t)n_pix * s_pass_req * 3ull * 4ull * 2ull;
+        const uint64_t budget = have * 8 / 10 > result_b ? have * 8 / 10 - result_b : 0;
+        const uint64_t per = bytes_per_pool_path(p.n_dir_sample, max_depth);
+        while (pool64 * per > budget && pool64 > 3 * 4096) pool64 /= 2;
     }
     // two pools (each half the paths) once a pass is big enough to keep both busy
     int n_pools = sc->n_pools;

@@ -96,7 +96,7 @@ typedef struct {
     /* pixel-tile partition (multi-GPU): pixel (i,j) is owned iff ((j/tile)*ceil(W/tile) + i/tile) % nranks == rank */
     int32_t tile_size, rank, nranks;
     /* launch shape; 0 => library default */
-    int32_t spp_per_pass;  /* samples per pixel in flight per pass (sizes the per-pass result buffer) */
+    int32_t spp_per_pass;  /* samples per pixel in flight per pass (sizes the per-pass result buffer); 0: chosen by the library so that a pass carries many pools of samples */
     int32_t pool_paths;    /* wavefront pool capacity in channel-paths */
     int32_t max_depth;     /* clamp-stack levels per path; 0 => derived from rr_rate (P[deeper] < 1e-12) */
 } mcpt_params;

@@ -406,6 +406,19 @@ def test_full_size_config2(pkg, oracle, hip):
     assert np.corrcoef(a.ravel(), b.ravel())[0, 1] > 0.97  # (measured 0.981: the oracle frame has 128 spp per pixel, the blocks 16 384)
 
 
+def test_default_pass_size_is_chosen_for_the_frame(pkg, hip):
+    """spp_per_pass 0: the library picks the pass size so that a pass carries many pools' worth of samples (a small frame -- or one rank's
+    share of a frame -- with many spp gets long passes instead of 32 spp each: render_impl, tools/pass_size.py).  Same frame, same work,
+    fewer wavefront iterations."""
+    sd = pkg.scenes.chess_scene(width=480, height=270, spp=512)
+    hs = hip.HipScene(sd)
+    auto, sa = hs.render(spp=512, seed=6)
+    fixed, sf = hs.render(spp=512, seed=6, spp_per_pass=32)
+    assert np.array_equal(auto, fixed, equal_nan=True)
+    assert (sa.vertices, sa.shaded, sa.shadow_rays) == (sf.vertices, sf.shaded, sf.shadow_rays)
+    assert sa.iterations * 2 < sf.iterations, (sa.iterations, sf.iterations)
+
+
 def test_largest_pass_path_ids_beyond_2_to_the_31(pkg, hip, monkeypatch):
     """The largest pass the library forms: path ids (pixel x sample-of-the-pass x channel) are 32-bit and a pass is cut so that they stay
     below 2^32 (render_impl).  A 3840x2160 chess frame with 128 spp in ONE pass has ids up to 3.18e9 -- beyond 2^31, where a signed index
