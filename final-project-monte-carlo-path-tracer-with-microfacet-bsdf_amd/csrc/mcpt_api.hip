@@ -151,6 +151,7 @@ struct Knobs {
     bool overlap = true;        // MCPT_OVERLAP=0: one stream instead of three
     bool queue_ahead = true;    // MCPT_QUEUE_AHEAD=0: wait for the counters before launching the chains
     bool timing = true;         // MCPT_TIMING=0: no per-kernel HIP events
+    bool verbose = false;       // MCPT_RENDER_VERBOSE=1: a line per render call on stderr (pass size, pool, time of the allocations)
     int pools = 1;              // MCPT_POOLS=2: two pools on two host threads
     int drain_batch = 4;        // MCPT_DRAIN_BATCH: iterations per host sync in the drain tail
     uint64_t pool_min_work = 1ull << 20;  // MCPT_POOL_MIN_WORK: smallest pass (samples) that uses two pools
@@ -171,6 +172,7 @@ struct Knobs {
         overlap = !off("MCPT_OVERLAP");
         queue_ahead = !off("MCPT_QUEUE_AHEAD");
         timing = !off("MCPT_TIMING");
+        verbose = std::getenv("MCPT_RENDER_VERBOSE") != nullptr;
         sky_cull = !off("MCPT_SKY_CULL");
         small_scene = !off("MCPT_SMALL_SCENE");
         const char *v;
@@ -747,7 +749,8 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     // or the pool runs half empty between passes.  Measured (tools/pass_size.py, chess 1080p spp 2048; the pool holds 13.4 M samples): 1.2 M
     // traced pixels x 32 spp (3x the pool) 4263 Msamples/s, x 64 4684, x 128 4907, x 256 4997, x 512 5010, x 1024 / 2048 4880 (the result buffer
     // grows with the pass); one rank of eight (0.15 M pixels): 32 spp 2317, 256 4282, 512 4610, 1024 4732, 2048 4769.  Chosen: the power
-    // of two that makes a pass at least 24 pools' worth of samples, between 32 spp and the call's own spp, within a quarter of the free memory.
+    // of two that makes a pass at least 16 pools' worth of samples (256 spp for the 1080p chess frame: 5.5 GB of result buffers; 2048 for an eighth
+    // of it), between 32 spp and the call's own spp, within a quarter of the free memory.
     // (device memory this call may use: what is free now plus what this scene's workspace and result buffer already hold; other tenants
     // of the GPU, a second scene, replicas of one group that share the device -- a rehearsal on a one-GPU box -- each take their share)
     uint64_t have = 0;
@@ -764,7 +767,7 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     }
     int s_pass_req = p.spp_per_pass;  // what the result buffer is sized for
     if (s_pass_req <= 0) {
-        const uint64_t want = 24ull * (pool64 / 3) / std::max<uint32_t>(n_pix, 1u) + 1ull;
+        const uint64_t want = 16ull * (pool64 / 3) / std::max<uint32_t>(n_pix, 1u) + 1ull;
         int cap = 32;
         while (cap < p.spp && cap < (1 << 20)) cap *= 2;  // (no larger than the call needs: the buffer of a short call stays small)
         s_pass_req = 32;
@@ -797,6 +800,7 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
         return MCPT_OK;
     }
     // (n_pix == 0 with owned pixels: every one of them was culled; the loop below then has no samples to issue and falls through)
+    const auto t_alloc0 = std::chrono::steady_clock::now();
     for (int k = 0; k < n_pools; ++k) HIP_TRY(ensure_workspace(sc->pools[k], pool, p.n_dir_sample, max_depth, stack_uses_retry(sc->view.height)));
     // two halves: a pass accumulates from one while the next pass fills the other (one half with a single pass)
     const size_t half_floats = (size_t)n_pix * s_pass * 3;
@@ -804,6 +808,9 @@ int render_impl(mcpt_scene *sc, const mcpt_camera *cam, const mcpt_params *pp, f
     // both halves are allocated, for the REQUESTED pass size, even when this call needs less: a later call with more or longer passes
     // (a warm-up followed by the real frame) must not pay a multi-GB hipFree + hipMalloc
     HIP_TRY(sh.result.alloc((size_t)n_pix * s_pass_req * 3 * (n_pools == 1 ? 2 : 1)));
+    if (sc->knobs.verbose)
+        std::fprintf(stderr, "[mcpt render] %u traced pixels, pass %d spp, pool %u paths; set-up before the allocations %.1f ms, workspace + result buffers %.1f ms\n", n_pix, s_pass,
+                     pool, std::chrono::duration<double, std::milli>(t_alloc0 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc0).count());
 
     RenderConst C;
     std::memset(&C, 0, sizeof C);
