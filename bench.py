@@ -354,7 +354,7 @@ def main():
         pkg.pngio.write_png(args.save_png, img)
 
     out = {
-        "metric": "Msamples/s (pixels x spp), chess scene 1920x1080, PSNR vs CPU",
+        "metric": "Msamples/s (pixels x spp), %s scene %dx%d, PSNR vs CPU" % (args.scene, W, H),  # (the default run: chess scene 1920x1080, BASELINE's metric)
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "ranks": ranks_seen, "backend": args.backend if distributed else None, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
