@@ -11,6 +11,7 @@ def run(budget, seed, verbose=True):
     """Renders random configurations for `budget` seconds; returns (variant renders, mismatches)."""
     rng = np.random.default_rng(seed)
     t0, n, bad = time.time(), 0, 0
+    t_report = t0
     while time.time() - t0 < budget:
         scene = str(rng.choice(["cornell_demo", "cornell_rc", "chess", "chess"]))
         w, h, spp = int(rng.integers(8, 400)), int(rng.integers(8, 260)), int(rng.integers(1, 24))
@@ -18,7 +19,7 @@ def run(budget, seed, verbose=True):
         sd.rr_rate = float(rng.choice([0.2, 0.4, 0.7, 0.9]))
         if rng.random() < 0.3:
             sd.camera["use_dof"] = int(rng.integers(0, 2))
-        kw = dict(spp=spp, seed=int(rng.integers(0, 1000)), n_dir_sample=int(rng.choice([1, 3, 4, 8])), spp_per_pass=int(rng.integers(1, spp + 1)))
+        kw = dict(spp=spp, seed=int(rng.integers(0, 1000)), n_dir_sample=int(rng.choice([1, 3, 4, 8])), spp_per_pass=int(rng.integers(0, spp + 1)))  # (0: the library's choice)
         os.environ.pop("MCPT_SKY_CULL", None)
         os.environ.pop("MCPT_SMALL_SCENE", None)
         ref, st0 = pkg.HipScene(sd, builder="sah", instancing=False).render(**kw)
@@ -46,6 +47,9 @@ def run(budget, seed, verbose=True):
                 if verbose:
                     print("MISMATCH", scene, w, h, kw, v, extra, nr, differing, flush=True)
             hs.close()
+        if verbose and time.time() - t_report > 60:  # (a sign of life: the GPU pool's watchdog ends a silent run after seven minutes)
+            t_report = time.time()
+            print("stress: %d variant renders so far, %d mismatches" % (n, bad), flush=True)
     os.environ.pop("MCPT_SKY_CULL", None)
     os.environ.pop("MCPT_SMALL_SCENE", None)
     return n, bad
